@@ -1,0 +1,138 @@
+/*
+ * swmi.h -- C ABI of the MI355X-native Smith-Waterman batch aligner (libswmi.so).
+ *
+ * This is the drop-in boundary for ONE hot path of elizabethfong/SparkSmithWaterman:
+ * the matrix fill + tied-maximum search + traceback that
+ *     JavaRDD.mapToPair(new MapRef())                 src/sw/Distribution.java:337-338
+ *       -> MapRef.call(tuple)                         src/sw/Distribution.java:403-436
+ *         -> SmithWaterman.OptAlignments.call(...)    src/sw/SmithWaterman.java:62-92
+ * runs once per (reference, read) pair.  The reference has no FFI of its own; the
+ * entry points below are what a JNI binding for that seam binds (INTEGRATION.md
+ * shows the Java/JNI side).  Plain C types only: pointers, sizes, POD structs.
+ *
+ * Conventions
+ *   - every function returning int returns SWMI_OK (0) or a negative swmi_status;
+ *     the message for the last failure on the calling thread: swmi_last_error().
+ *   - sequences are byte strings (Java chars narrowed to ISO-8859-1).  Two bases are
+ *     equal iff Character.toUpperCase of the two chars is equal, as AlignmentScore
+ *     tests (src/sw/SmithWaterman.java:309-318), reproduced exactly for Latin-1.  A JNI
+ *     caller holding chars above U+00FF must canonicalise them first.
+ *   - a batch is the cross product refs x reads, pair index = ref * n_reads + read:
+ *     the order in which MapRef.call loops (Distribution.java:419-426).
+ *   - a context is bound to one GPU and owns one HIP stream; calls on one context
+ *     are serialised internally, use one context per host thread for concurrency
+ *     (Spark runs MapRef on every executor thread).
+ *   - there is NO CPU fallback: if no gfx950 device / kernel image is usable the
+ *     calls fail with SWMI_ERR_NO_DEVICE.
+ */
+#ifndef SWMI_H
+#define SWMI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SWMI_ABI_VERSION 1
+
+typedef enum swmi_status {
+    SWMI_OK               =  0,
+    SWMI_ERR_INVALID      = -1,  /* bad argument (null pointer, non-monotone offsets, ...)   */
+    SWMI_ERR_NO_DEVICE    = -2,  /* no usable MI355X / HIP runtime error at start-up          */
+    SWMI_ERR_HIP          = -3,  /* a HIP call failed; see swmi_last_error()                  */
+    SWMI_ERR_NOMEM        = -4,  /* host or device allocation failed                          */
+    SWMI_ERR_UNSUPPORTED  = -5,  /* e.g. alignTypes a/i/d not pairwise distinct, len >= 2^30  */
+    SWMI_ERR_RANGE        = -6   /* index out of range in an accessor                         */
+} swmi_status;
+
+/* Which reference aligner's tie-breaking is reproduced. */
+#define SWMI_TIE_SERIAL 0  /* SmithWaterman.GetCellScore, '>=' chain: a > i > d (SmithWaterman.java:223-249);
+                              max cells in row-major order (SmithWaterman.java:157-185)                        */
+#define SWMI_TIE_STRICT 1  /* DistributedSW.GetCellScore, '>' chain: d > i > a (DistributedSW.java:305-330);
+                              max cells per anti-diagonal, ascending j (DistributedSW.java:209-239), then a
+                              stable sort of the alignments by beginning (DistributedSW.java:480)              */
+
+/* alignScores {match, mismatch, gap} and alignTypes {a, i, d, none}: the two arrays
+ * OptAlignments.call takes (SmithWaterman.java:47-57); defaults Distribution.java:36-37. */
+typedef struct swmi_params {
+    int32_t match;       /* default  5 */
+    int32_t mismatch;    /* default -3 */
+    int32_t gap;         /* default -4 (linear) */
+    int32_t tie_mode;    /* SWMI_TIE_SERIAL | SWMI_TIE_STRICT */
+    char    types[4];    /* default {'a','i','d','-'}; only used to validate distinctness */
+} swmi_params;
+
+typedef struct swmi_ctx    swmi_ctx;     /* per-(thread, device) context                  */
+typedef struct swmi_batch  swmi_batch;   /* sequences resident in HBM + device workspaces */
+
+/* ---- library / context --------------------------------------------------------- */
+int         swmi_abi_version(void);
+const char *swmi_last_error(void);                       /* thread-local, never NULL */
+int         swmi_device_count(int *count);
+int         swmi_create(int device, swmi_ctx **out);     /* device = HIP ordinal      */
+void        swmi_destroy(swmi_ctx *ctx);
+void        swmi_default_params(swmi_params *p);
+
+/* Tuning knobs (all optional).  cell_cap: tied-maximum cells kept per pair in the
+ * fast path (pairs with more are re-run on the GPU with an exact-size list);
+ * max_workspace_bytes: cap on the direction-field arena (larger batches are run in
+ * chunks); profiling != 0 brackets every kernel with HIP events. */
+int         swmi_set_option(swmi_ctx *ctx, const char *name, int64_t value);
+
+/* ---- staged path: upload once, run many times (what bench.py times) ------------- */
+/* ref_off/read_off have n+1 entries, off[0] == 0, non-decreasing; lengths < 2^30.  */
+int  swmi_batch_upload(swmi_ctx *ctx,
+                       const uint8_t *ref_bytes, const uint64_t *ref_off, uint32_t n_refs,
+                       const uint8_t *read_bytes, const uint64_t *read_off, uint32_t n_reads,
+                       swmi_batch **out);
+/* Fill + direction field + max-cell lists + device traceback for every pair, then
+ * the compact result records device->host.  Synchronous on return. */
+int  swmi_batch_run(swmi_ctx *ctx, swmi_batch *b, const swmi_params *p);
+void swmi_batch_free(swmi_ctx *ctx, swmi_batch *b);
+
+/* Stage timings of the last swmi_batch_run with option "profiling" = 1 (ms, HIP events
+ * on the context's stream): fill kernel, traceback kernel, D2H; launches = number of
+ * fill launches the figures sum over. */
+typedef struct swmi_timing {
+    float    fill_ms, traceback_ms, d2h_ms, total_ms;
+    uint32_t fill_launches, rerun_pairs;
+    uint64_t cells;             /* sum of m*n over the pairs of the run            */
+    uint64_t dir_bytes;         /* direction-field bytes written                   */
+} swmi_timing;
+int  swmi_batch_timing(const swmi_batch *b, swmi_timing *t);
+
+/* ---- results of the last run (host memory owned by the batch) ------------------- */
+#define SWMI_PAIR_DEGENERATE 0x1u   /* max score 0: every one of the m*n cells is a "max cell" and
+                                       yields (0,"","") -- SmithWaterman.java:154,182-185,378-380 */
+uint64_t swmi_batch_n_pairs(const swmi_batch *b);
+int      swmi_pair_score(const swmi_batch *b, uint64_t pair, int32_t *score);
+int      swmi_pair_n_alignments(const swmi_batch *b, uint64_t pair, uint64_t *n, uint32_t *flags);
+/* k-th alignment of the pair in OptAlignments order.  *ref_aln / *read_aln point to
+ * NUL-terminated strings owned by the batch (valid until the next run/free);
+ * characters keep the caller's original case, gaps are '_' (SmithWaterman.java:356). */
+int      swmi_pair_alignment(swmi_batch *b, uint64_t pair, uint64_t k,
+                             int32_t *begin, int32_t *end_i, int32_t *end_j,
+                             const char **ref_aln, const char **read_aln, uint32_t *len);
+
+/* ---- MapRef view: per reference, over all reads (Distribution.java:403-436) ------ */
+/* total = sum over reads of the pair scores (Java int, wrapping) (:424). */
+int      swmi_ref_total(const swmi_batch *b, uint32_t ref, int32_t *total);
+/* matchSites = the reads' alignment lists concatenated in read order (:425), then
+ * stably sorted by ascending begin (:428, MatchSiteComp :691-694). */
+int      swmi_ref_n_match_sites(swmi_batch *b, uint32_t ref, uint64_t *n);
+int      swmi_ref_match_site(swmi_batch *b, uint32_t ref, uint64_t k, int32_t *begin,
+                             const char **ref_aln, const char **read_aln, uint32_t *len);
+
+/* ---- one-shot path: what a per-partition JNI call binds -------------------------- */
+/* upload + run; results are read with the accessors above; free with swmi_batch_free. */
+int  swmi_align_batch(swmi_ctx *ctx, const swmi_params *p,
+                      const uint8_t *ref_bytes, const uint64_t *ref_off, uint32_t n_refs,
+                      const uint8_t *read_bytes, const uint64_t *read_off, uint32_t n_reads,
+                      swmi_batch **out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SWMI_H */

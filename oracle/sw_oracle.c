@@ -27,8 +27,8 @@
  *   src/sw/Distribution.java:403-436   MapRef.call          -> sw_oracle_map_ref()
  *   src/sw/Distribution.java:691-694   MatchSiteComp        -> stable sort by begin
  *
- * Domain: sequences are byte strings.  Java's Character.toUpperCase is restated
- * for ASCII only (a-z -> A-Z); bytes >= 0x80 compare raw.  All score arithmetic
+ * Domain: sequences are byte strings holding ISO-8859-1 characters.  Java's
+ * Character.toUpperCase is restated exactly for that range (see up()).  All score arithmetic
  * is Java int (32-bit two's complement, wrapping), done here in uint32_t.
  */
 #define _POSIX_C_SOURCE 200809L
@@ -60,9 +60,13 @@ typedef struct {
 
 static char EMPTY[1] = { 0 };
 
-/* SmithWaterman.java:311-312 -- Character.toUpperCase, ASCII subset. */
+/* SmithWaterman.java:311-312 -- Character.toUpperCase restricted to ISO-8859-1 input:
+ * a-z and 0xE0-0xFE (except the division sign 0xF7) drop 0x20; 0xB5 (micro) and 0xFF (y-diaeresis)
+ * map outside Latin-1 to characters nothing else maps to, so they only equal themselves. */
 static inline unsigned char up(unsigned char c) {
-    return (c >= 'a' && c <= 'z') ? (unsigned char)(c - 32) : c;
+    if (c >= 'a' && c <= 'z') return (unsigned char)(c - 32);
+    if (c >= 0xE0 && c <= 0xFE && c != 0xF7) return (unsigned char)(c - 32);
+    return c;
 }
 
 /* SmithWaterman.java:309-318 */

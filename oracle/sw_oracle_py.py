@@ -21,8 +21,11 @@ def _i32(x):
 
 
 def _upper(c):
-    # Character.toUpperCase, ASCII subset (the oracle's stated domain)
-    return c.upper() if "a" <= c <= "z" else c
+    # Character.toUpperCase for ISO-8859-1 input (the oracle's stated domain)
+    o = ord(c)
+    if 0x61 <= o <= 0x7A or (0xE0 <= o <= 0xFE and o != 0xF7):
+        return chr(o - 32)
+    return c
 
 
 def ins_del_score(cell_score, gap_score):            # :277-280

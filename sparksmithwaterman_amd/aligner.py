@@ -1,0 +1,124 @@
+"""Context / Batch: thin object wrappers over the C ABI (include/swmi.h)."""
+import ctypes as C
+
+from . import _capi
+from ._capi import Params, Timing, check
+
+DEFAULT_SCORES = (5, -3, -4)              # Distribution.java:36  {match, mismatch, gap}
+DEFAULT_TYPES = ("a", "i", "d", "-")      # Distribution.java:37
+
+
+def make_params(align_scores=None, align_types=None, tie_mode=_capi.TIE_SERIAL):
+    sc = DEFAULT_SCORES if align_scores is None else tuple(int(x) for x in align_scores)
+    ty = DEFAULT_TYPES if align_types is None else tuple(align_types)
+    if len(sc) != 3 or len(ty) != 4:
+        raise ValueError("alignScores needs 3 entries and alignTypes 4")
+    p = Params()
+    p.match, p.mismatch, p.gap = sc
+    p.tie_mode = tie_mode
+    p.types = b"".join(_capi.as_bytes(t)[:1] for t in ty)
+    return p
+
+
+class Context:
+    """One GPU + one HIP stream (swmi_ctx).  Use one per host thread."""
+
+    def __init__(self, device=0):
+        self._lib = _capi.load()
+        h = C.c_void_p()
+        check(self._lib.swmi_create(int(device), C.byref(h)))
+        self._h = h
+        self.device = int(device)
+
+    def set_option(self, name, value):
+        check(self._lib.swmi_set_option(self._h, name.encode(), int(value)))
+
+    def upload(self, refs, reads):
+        """Sequences -> HBM.  refs/reads: lists of str or bytes."""
+        return Batch(self, refs, reads)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.swmi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Batch:
+    """refs x reads resident on the GPU (swmi_batch); pair index = ref * n_reads + read."""
+
+    def __init__(self, ctx, refs, reads):
+        self._ctx = ctx
+        self._lib = ctx._lib
+        self.n_refs, self.n_reads = len(refs), len(reads)
+        rb, ro = _capi.pack(refs)
+        qb, qo = _capi.pack(reads)
+        h = C.c_void_p()
+        check(self._lib.swmi_batch_upload(ctx._h, rb, ro, self.n_refs, qb, qo, self.n_reads, C.byref(h)))
+        self._h = h
+
+    def run(self, params=None):
+        """Fill + traceback on the GPU for every pair, results to the host.  Synchronous."""
+        p = params if params is not None else make_params()
+        check(self._lib.swmi_batch_run(self._ctx._h, self._h, C.byref(p)))
+        return self
+
+    def timing(self):
+        t = Timing()
+        check(self._lib.swmi_batch_timing(self._h, C.byref(t)))
+        return t
+
+    # ---- per pair -------------------------------------------------------------------
+    def score(self, pair):
+        v = C.c_int32()
+        check(self._lib.swmi_pair_score(self._h, pair, C.byref(v)))
+        return v.value
+
+    def n_alignments(self, pair):
+        n, f = C.c_uint64(), C.c_uint32()
+        check(self._lib.swmi_pair_n_alignments(self._h, pair, C.byref(n), C.byref(f)))
+        return n.value, f.value
+
+    def alignment(self, pair, k, with_cell=False):
+        b, ei, ej = C.c_int32(), C.c_int32(), C.c_int32()
+        r, q, ln = C.c_char_p(), C.c_char_p(), C.c_uint32()
+        check(self._lib.swmi_pair_alignment(self._h, pair, k, C.byref(b), C.byref(ei), C.byref(ej),
+                                            C.byref(r), C.byref(q), C.byref(ln)))
+        rec = (b.value, (r.value.decode("latin-1"), q.value.decode("latin-1")))
+        return rec + ((ei.value, ej.value),) if with_cell else rec
+
+    def alignments(self, pair, with_cell=False):
+        n, _ = self.n_alignments(pair)
+        return [self.alignment(pair, k, with_cell) for k in range(n)]
+
+    # ---- MapRef view -----------------------------------------------------------------
+    def ref_total(self, ref):
+        v = C.c_int32()
+        check(self._lib.swmi_ref_total(self._h, ref, C.byref(v)))
+        return v.value
+
+    def ref_match_sites(self, ref):
+        n = C.c_uint64()
+        check(self._lib.swmi_ref_n_match_sites(self._h, ref, C.byref(n)))
+        out = []
+        b, r, q, ln = C.c_int32(), C.c_char_p(), C.c_char_p(), C.c_uint32()
+        for k in range(n.value):
+            check(self._lib.swmi_ref_match_site(self._h, ref, k, C.byref(b), C.byref(r), C.byref(q), C.byref(ln)))
+            out.append((b.value, (r.value.decode("latin-1"), q.value.decode("latin-1"))))
+        return out
+
+    def free(self):
+        if getattr(self, "_h", None):
+            self._lib.swmi_batch_free(self._ctx._h, self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

@@ -1,0 +1,829 @@
+// swmi_api.cpp -- host runtime behind the C ABI of include/swmi.h.
+//
+// Owns device memory, the HIP stream, batching/chunking, the overflow re-runs and the
+// host-side assembly of results (the part of the reference that builds Java Strings from
+// the traceback stack, src/sw/SmithWaterman.java:418-431, and MapRef's aggregation,
+// src/sw/Distribution.java:403-436).  All DP arithmetic and every traceback step run in
+// the gfx950 kernels of swmi_kernels.hip: there is no CPU implementation of the
+// algorithm in this library, and every entry point fails if no GPU is usable.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/swmi.h"
+#include "swmi_device.h"
+
+extern "C" hipError_t swmi_launch_fill(const FillArgs *a, hipStream_t st);
+extern "C" hipError_t swmi_launch_traceback(const TraceArgs *a, hipStream_t st);
+
+// ------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(e_ == hipErrorOutOfMemory ? SWMI_ERR_NOMEM : SWMI_ERR_HIP,            \
+                        "%s failed: %s", #expr, hipGetErrorString(e_));                       \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------
+// device buffer with capacity (grow-only)
+// ------------------------------------------------------------------------------------------
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return SWMI_OK;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) { p = nullptr; return fail(SWMI_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); }
+        cap = bytes;
+        return SWMI_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T *as() const { return (T *)p; }
+};
+
+struct PinnedBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return SWMI_OK;
+        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+        hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+        if (e != hipSuccess) { p = nullptr; return fail(SWMI_ERR_NOMEM, "hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); }
+        cap = bytes;
+        return SWMI_OK;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
+// ------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------
+struct swmi_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    // options
+    uint32_t cell_cap = 64;
+    uint64_t max_workspace_bytes = 32ull << 30;
+    int profiling = 0;
+    uint64_t arena_words_per_pair = 48;     // first guess of the record arena, grows on demand
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+};
+
+// one alignment as parsed from the arena
+struct HostAln {
+    uint32_t rank;
+    int32_t begin, end_i, end_j;
+    uint32_t n_ops;
+    uint64_t ops_at;        // index into swmi_batch::ops (dwords)
+    int64_t str_id = -1;    // index into the materialised-string cache
+};
+
+struct PairRes {
+    int32_t score = 0;
+    uint32_t flags = 0;
+    uint64_t n_cells = 0;
+    uint64_t first = 0;     // index of the pair's first HostAln (ordered)
+    uint64_t count = 0;     // alignment records present (0 when degenerate)
+};
+
+struct SiteRef { uint64_t pair; uint64_t k; int32_t begin; };
+
+struct swmi_batch {
+    uint32_t n_refs = 0, n_reads = 0;
+    // original bytes (for string building: characters keep their case) and offsets
+    std::vector<uint8_t> ref_bytes, read_bytes;
+    std::vector<uint64_t> ref_off, read_off;
+    std::vector<SeqDesc> ref_desc, read_desc;
+    // device
+    DevBuf d_seqw, d_refs, d_reads, d_pairs, d_dir, d_seam, d_result, d_cells, d_cells_off, d_cells_cap;
+    PinnedBuf h_result;
+    // per run
+    swmi_params params{};
+    bool has_run = false;
+    std::vector<uint32_t> order;            // sorted position -> pair index (ref * n_reads + read)
+    std::vector<PairRes> pairs;             // by pair index
+    std::vector<HostAln> alns;              // grouped by pair, ordered as OptAlignments returns them
+    std::vector<uint32_t> ops;              // concatenated op words of all records
+    std::vector<std::string> str_ref, str_read;   // materialised alignments
+    // MapRef view cache
+    std::vector<int8_t> ref_view_ready;
+    std::vector<std::vector<SiteRef>> ref_sites;
+    std::vector<uint64_t> ref_degenerate;   // leading (0,"","") sites per ref
+    swmi_timing timing{};
+};
+
+// ------------------------------------------------------------------------------------------
+// library / context
+// ------------------------------------------------------------------------------------------
+extern "C" int swmi_abi_version(void) { return SWMI_ABI_VERSION; }
+
+extern "C" const char *swmi_last_error(void) { return g_err.c_str(); }
+
+extern "C" int swmi_device_count(int *count) {
+    if (!count) return fail(SWMI_ERR_INVALID, "count is null");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return fail(SWMI_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    *count = n;
+    return SWMI_OK;
+}
+
+extern "C" void swmi_default_params(swmi_params *p) {
+    if (!p) return;
+    p->match = 5; p->mismatch = -3; p->gap = -4;            // Distribution.java:36
+    p->tie_mode = SWMI_TIE_SERIAL;
+    p->types[0] = 'a'; p->types[1] = 'i'; p->types[2] = 'd'; p->types[3] = '-';   // Distribution.java:37
+}
+
+extern "C" int swmi_create(int device, swmi_ctx **out) {
+    if (!out) return fail(SWMI_ERR_INVALID, "out is null");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(SWMI_ERR_NO_DEVICE, "no HIP device available (%s); this library has no CPU fallback",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    if (device < 0 || device >= n) return fail(SWMI_ERR_INVALID, "device %d out of range [0,%d)", device, n);
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) return fail(SWMI_ERR_NO_DEVICE, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(SWMI_ERR_NO_DEVICE, "device %d is %s; the kernels are built for gfx950 (MI355X) only",
+                    device, prop.gcnArchName);
+    e = hipSetDevice(device);
+    if (e != hipSuccess) return fail(SWMI_ERR_NO_DEVICE, "hipSetDevice: %s", hipGetErrorString(e));
+    std::unique_ptr<swmi_ctx> c(new swmi_ctx);
+    c->device = device;
+    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) return fail(SWMI_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+    for (auto &ev : c->ev) {
+        e = hipEventCreate(&ev);
+        if (e != hipSuccess) return fail(SWMI_ERR_HIP, "hipEventCreate: %s", hipGetErrorString(e));
+    }
+    *out = c.release();
+    return SWMI_OK;
+}
+
+extern "C" void swmi_destroy(swmi_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    for (auto &ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" int swmi_set_option(swmi_ctx *ctx, const char *name, int64_t value) {
+    if (!ctx || !name) return fail(SWMI_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> g(ctx->mu);
+    if (!strcmp(name, "cell_cap")) {
+        if (value < 1 || value > (1 << 20)) return fail(SWMI_ERR_INVALID, "cell_cap out of range");
+        ctx->cell_cap = (uint32_t)value;
+    } else if (!strcmp(name, "max_workspace_bytes")) {
+        if (value < (1 << 20)) return fail(SWMI_ERR_INVALID, "max_workspace_bytes too small");
+        ctx->max_workspace_bytes = (uint64_t)value;
+    } else if (!strcmp(name, "profiling")) {
+        ctx->profiling = value != 0;
+    } else if (!strcmp(name, "arena_words_per_pair")) {
+        if (value < 1) return fail(SWMI_ERR_INVALID, "arena_words_per_pair out of range");
+        ctx->arena_words_per_pair = (uint64_t)value;
+    } else {
+        return fail(SWMI_ERR_INVALID, "unknown option '%s'", name);
+    }
+    return SWMI_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// sequence encoding
+// ------------------------------------------------------------------------------------------
+// Canonical base codes: Character.toUpperCase restricted to ISO-8859-1 input (SmithWaterman.java:311-312:
+// a-z and 0xE0-0xFE except 0xF7 drop 0x20; 0xB5 and 0xFF map outside Latin-1 and only equal themselves) followed by a permutation of the byte values that puts A,C,G,T on
+// 0..3, so that code(x) == code(y)  <=>  toUpperCase(x) == toUpperCase(y).
+static const uint8_t *code_table() {
+    static uint8_t T[256];
+    static bool init = false;
+    if (!init) {
+        uint8_t perm[256];
+        for (int i = 0; i < 256; i++) perm[i] = (uint8_t)i;
+        const uint8_t acgt[4] = {'A', 'C', 'G', 'T'};
+        for (int k = 0; k < 4; k++) std::swap(perm[acgt[k]], perm[k]);
+        for (int i = 0; i < 256; i++) {
+            int u = i;
+            if ((i >= 'a' && i <= 'z') || (i >= 0xE0 && i <= 0xFE && i != 0xF7)) u = i - 32;
+            T[i] = perm[u];
+        }
+        init = true;
+    }
+    return T;
+}
+
+static void encode_sequences(const uint8_t *bytes, const uint64_t *off, uint32_t n,
+                             std::vector<uint32_t> &seqw, std::vector<SeqDesc> &desc) {
+    const uint8_t *T = code_table();
+    desc.resize(n);
+    for (uint32_t s = 0; s < n; s++) {
+        const uint64_t len = off[s + 1] - off[s];
+        const uint8_t *p = bytes + off[s];
+        SeqDesc d{};
+        d.len = (uint32_t)len;
+        d.boff = (uint32_t)seqw.size();
+        const size_t bw = (len + 3) / 4;
+        seqw.resize(seqw.size() + bw + SWMI_SEQ_PAD_WORDS, 0u);
+        bool acgt = true;
+        uint32_t *bwp = seqw.data() + d.boff;
+        for (uint64_t k = 0; k < len; k++) {
+            const uint32_t c = T[p[k]];
+            acgt &= c < 4;
+            bwp[k >> 2] |= c << (8 * (k & 3));
+        }
+        d.poff = SWMI_NO_PACKED;
+        if (acgt) {
+            d.poff = (uint32_t)seqw.size();
+            const size_t pw = (len + 15) / 16;
+            seqw.resize(seqw.size() + pw + SWMI_SEQ_PAD_WORDS, 0u);
+            uint32_t *pp = seqw.data() + d.poff;
+            for (uint64_t k = 0; k < len; k++) pp[k >> 4] |= (uint32_t)T[p[k]] << (2 * (k & 15));
+        }
+        desc[s] = d;
+    }
+}
+
+static int check_offsets(const uint64_t *off, uint32_t n, const char *what) {
+    if (!off) return fail(SWMI_ERR_INVALID, "%s offsets are null", what);
+    if (off[0] != 0) return fail(SWMI_ERR_INVALID, "%s offsets must start at 0", what);
+    for (uint32_t k = 0; k < n; k++) {
+        if (off[k + 1] < off[k]) return fail(SWMI_ERR_INVALID, "%s offsets decrease at %u", what, k);
+        if (off[k + 1] - off[k] >= (1ull << 30))
+            return fail(SWMI_ERR_UNSUPPORTED, "%s %u is longer than 2^30-1 bases", what, k);
+    }
+    return SWMI_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// upload
+// ------------------------------------------------------------------------------------------
+extern "C" void swmi_batch_free(swmi_ctx *ctx, swmi_batch *b) {
+    if (!b) return;
+    if (ctx) (void)hipSetDevice(ctx->device);
+    b->d_seqw.release(); b->d_refs.release(); b->d_reads.release(); b->d_pairs.release();
+    b->d_dir.release(); b->d_seam.release(); b->d_result.release(); b->d_cells.release();
+    b->d_cells_off.release(); b->d_cells_cap.release();
+    b->h_result.release();
+    delete b;
+}
+
+extern "C" int swmi_batch_upload(swmi_ctx *ctx,
+                                 const uint8_t *ref_bytes, const uint64_t *ref_off, uint32_t n_refs,
+                                 const uint8_t *read_bytes, const uint64_t *read_off, uint32_t n_reads,
+                                 swmi_batch **out) {
+    if (!ctx || !out) return fail(SWMI_ERR_INVALID, "null argument");
+    *out = nullptr;
+    int rc;
+    if ((rc = check_offsets(ref_off, n_refs, "reference"))) return rc;
+    if ((rc = check_offsets(read_off, n_reads, "read"))) return rc;
+    if ((n_refs && ref_off[n_refs] && !ref_bytes) || (n_reads && read_off[n_reads] && !read_bytes))
+        return fail(SWMI_ERR_INVALID, "sequence bytes are null");
+    if ((uint64_t)n_refs * n_reads >= (1ull << 32))
+        return fail(SWMI_ERR_UNSUPPORTED, "more than 2^32-1 pairs in one batch");
+    std::lock_guard<std::mutex> g(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+
+    std::unique_ptr<swmi_batch> b(new swmi_batch);
+    b->n_refs = n_refs; b->n_reads = n_reads;
+    b->ref_off.assign(ref_off, ref_off + n_refs + 1);
+    b->read_off.assign(read_off, read_off + n_reads + 1);
+    b->ref_bytes.assign(ref_bytes, ref_bytes + ref_off[n_refs]);
+    b->read_bytes.assign(read_bytes, read_bytes + read_off[n_reads]);
+
+    std::vector<uint32_t> seqw;
+    seqw.reserve((ref_off[n_refs] + read_off[n_reads]) / 3 + 16ull * (n_refs + n_reads) + 16);
+    encode_sequences(ref_bytes, ref_off, n_refs, seqw, b->ref_desc);
+    encode_sequences(read_bytes, read_off, n_reads, seqw, b->read_desc);
+    if (seqw.size() >= (1ull << 32)) return fail(SWMI_ERR_UNSUPPORTED, "sequence image exceeds 16 GiB");
+    seqw.resize(seqw.size() + SWMI_SEQ_PAD_WORDS, 0u);
+
+    auto up = [&](DevBuf &d, const void *src, size_t bytes) -> int {
+        int r = d.reserve(bytes ? bytes : 4);
+        if (r) return r;
+        if (bytes) HIP_TRY(hipMemcpyAsync(d.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        return SWMI_OK;
+    };
+    if ((rc = up(b->d_seqw, seqw.data(), seqw.size() * 4))) { swmi_batch_free(ctx, b.release()); return rc; }
+    if ((rc = up(b->d_refs, b->ref_desc.data(), b->ref_desc.size() * sizeof(SeqDesc)))) { swmi_batch_free(ctx, b.release()); return rc; }
+    if ((rc = up(b->d_reads, b->read_desc.data(), b->read_desc.size() * sizeof(SeqDesc)))) { swmi_batch_free(ctx, b.release()); return rc; }
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { swmi_batch_free(ctx, b.release()); return fail(SWMI_ERR_HIP, "upload sync: %s", hipGetErrorString(e)); }
+    *out = b.release();
+    return SWMI_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// run
+// ------------------------------------------------------------------------------------------
+namespace {
+
+struct Work {            // one pair scheduled for a launch
+    uint32_t pair;       // ref * n_reads + read
+    uint64_t cells;      // m * n
+    uint64_t dir_words;
+    uint64_t seam_words;
+};
+
+struct RunState {
+    swmi_ctx *ctx;
+    swmi_batch *b;
+    FillArgs fa{};
+    TraceArgs ta{};
+    float fill_ms = 0, tb_ms = 0, d2h_ms = 0;
+    uint32_t launches = 0;
+};
+
+// layout of the device result block: [ArenaHdr | PairOut x np | arena words ...]
+inline size_t result_out_off() { return 64; }
+inline size_t result_arena_off(size_t np) { return (64 + np * sizeof(PairOut) + 255) & ~(size_t)255; }
+
+}  // namespace
+
+// Runs fill + traceback for `work` (already ordered), one chunk, and parses the records.
+// per-pair cell-list geometry: uniform (cap) when cells_cap_exact is empty, else exact per pair.
+static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, size_t hi,
+                     const std::vector<uint64_t> *cells_exact,
+                     std::vector<PairOut> &outs, std::vector<uint32_t> &arena_copy, uint64_t &arena_used) {
+    swmi_ctx *ctx = rs.ctx;
+    swmi_batch *b = rs.b;
+    const size_t np = hi - lo;
+    const uint32_t n_reads = b->n_reads;
+    int rc;
+
+    // pair descriptors, direction-field and seam offsets
+    std::vector<PairDesc> pd(np);
+    uint64_t dir_words = 0, seam_words = 0;
+    uint32_t max_path = 0;
+    for (size_t k = 0; k < np; k++) {
+        const Work &w = work[lo + k];
+        PairDesc d{};
+        d.ref_id = w.pair / n_reads;
+        d.read_id = w.pair % n_reads;
+        d.out_id = (uint32_t)k;
+        d.dir_off = dir_words;
+        d.seam_off = seam_words;
+        dir_words += w.dir_words;
+        seam_words += w.seam_words;
+        pd[k] = d;
+        max_path = std::max(max_path, b->ref_desc[d.ref_id].len + b->read_desc[d.read_id].len);
+    }
+    if ((rc = b->d_pairs.reserve(np * sizeof(PairDesc)))) return rc;
+    if ((rc = b->d_dir.reserve(std::max<uint64_t>(dir_words, 1) * 4))) return rc;
+    if ((rc = b->d_seam.reserve(std::max<uint64_t>(seam_words, 1) * 4))) return rc;
+    HIP_TRY(hipMemcpyAsync(b->d_pairs.p, pd.data(), np * sizeof(PairDesc), hipMemcpyHostToDevice, ctx->stream));
+    if (seam_words) HIP_TRY(hipMemsetAsync(b->d_seam.p, 0, seam_words * 4, ctx->stream));
+
+    // cell lists
+    std::vector<uint64_t> coff;
+    std::vector<uint32_t> ccap;
+    uint64_t cells_total = 0;
+    if (cells_exact) {
+        coff.resize(np); ccap.resize(np);
+        for (size_t k = 0; k < np; k++) {
+            coff[k] = cells_total;
+            ccap[k] = (uint32_t)std::min<uint64_t>((*cells_exact)[lo + k], 0xFFFFFFFFu);
+            cells_total += ccap[k];
+        }
+        if ((rc = b->d_cells_off.reserve(np * 8))) return rc;
+        if ((rc = b->d_cells_cap.reserve(np * 4))) return rc;
+        HIP_TRY(hipMemcpyAsync(b->d_cells_off.p, coff.data(), np * 8, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(b->d_cells_cap.p, ccap.data(), np * 4, hipMemcpyHostToDevice, ctx->stream));
+    } else {
+        cells_total = (uint64_t)np * ctx->cell_cap;
+    }
+    if ((rc = b->d_cells.reserve(std::max<uint64_t>(cells_total, 1) * sizeof(uint2)))) return rc;
+
+    const uint32_t lds_words = (max_path + 15) / 16 + 1;
+    if (lds_words * 4ull > 160 * 1024)
+        return fail(SWMI_ERR_UNSUPPORTED, "alignment path of up to %u ops does not fit the LDS staging buffer", max_path);
+
+    uint64_t arena_cap = std::max<uint64_t>(np * ctx->arena_words_per_pair, 1024);
+    std::vector<uint8_t> saved_outs;       // PairOut block carried across an arena re-allocation
+    for (int attempt = 0;; attempt++) {
+        const size_t a_off = result_arena_off(np);
+        if ((rc = b->d_result.reserve(a_off + arena_cap * 4))) return rc;
+        uint8_t *res = b->d_result.as<uint8_t>();
+        HIP_TRY(hipMemsetAsync(res, 0, 64, ctx->stream));
+        if (attempt > 0)
+            HIP_TRY(hipMemcpyAsync(res + result_out_off(), saved_outs.data(), saved_outs.size(),
+                                   hipMemcpyHostToDevice, ctx->stream));
+
+        FillArgs &fa = rs.fa;
+        fa.seqw = b->d_seqw.as<uint32_t>();
+        fa.refs = b->d_refs.as<SeqDesc>();
+        fa.reads = b->d_reads.as<SeqDesc>();
+        fa.pairs = b->d_pairs.as<PairDesc>();
+        fa.dir = b->d_dir.as<uint32_t>();
+        fa.seam = b->d_seam.as<int32_t>();
+        fa.out = (PairOut *)(res + result_out_off());
+        fa.cells = b->d_cells.as<uint2>();
+        fa.cells_off = cells_exact ? b->d_cells_off.as<uint64_t>() : nullptr;
+        fa.cells_cap = cells_exact ? b->d_cells_cap.as<uint32_t>() : nullptr;
+        fa.n_pairs = (uint32_t)np;
+        fa.cell_cap = ctx->cell_cap;
+        fa.match = b->params.match; fa.mismatch = b->params.mismatch; fa.gap = b->params.gap;
+        fa.strict = b->params.tie_mode == SWMI_TIE_STRICT;
+
+        TraceArgs &ta = rs.ta;
+        ta.seqw = fa.seqw; ta.refs = fa.refs; ta.reads = fa.reads; ta.pairs = fa.pairs;
+        ta.dir = fa.dir; ta.out = fa.out; ta.cells = fa.cells;
+        ta.cells_off = fa.cells_off; ta.cells_cap = fa.cells_cap;
+        ta.hdr = (ArenaHdr *)res;
+        ta.arena = (uint32_t *)(res + a_off);
+        ta.arena_cap_words = arena_cap;
+        ta.n_pairs = fa.n_pairs; ta.cell_cap = fa.cell_cap;
+        ta.match = fa.match; ta.mismatch = fa.mismatch; ta.gap = fa.gap; ta.strict = fa.strict;
+        ta.lds_words = lds_words;
+
+        if (attempt == 0) {       // the direction field survives an arena-overflow retry
+            if (ctx->profiling) HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
+            HIP_TRY(swmi_launch_fill(&fa, ctx->stream));
+            if (ctx->profiling) HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
+            rs.launches++;
+        }
+        if (ctx->profiling) HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
+        HIP_TRY(swmi_launch_traceback(&ta, ctx->stream));
+        if (ctx->profiling) HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
+
+        // one D2H of header + pair outputs + the whole arena guess
+        const size_t copy_bytes = a_off + arena_cap * 4;
+        if ((rc = b->h_result.reserve(copy_bytes))) return rc;
+        HIP_TRY(hipMemcpyAsync(b->h_result.p, res, copy_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        if (ctx->profiling) HIP_TRY(hipEventRecord(ctx->ev[4], ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (ctx->profiling) {
+            float ms = 0;
+            if (attempt == 0) { HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1])); rs.fill_ms += ms; }
+            HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3])); rs.tb_ms += ms;
+            HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4])); rs.d2h_ms += ms;
+        }
+        const uint8_t *h = (const uint8_t *)b->h_result.p;
+        const ArenaHdr *hdr = (const ArenaHdr *)h;
+        if (hdr->used_words > arena_cap) {         // records were dropped: grow to the exact need and redo the traceback
+            saved_outs.assign(h + result_out_off(), h + result_out_off() + np * sizeof(PairOut));
+            for (size_t k = 0; k < np; k++) ((PairOut *)saved_outs.data())[k].flags &= ~SWMI_F_ARENA_OVF;
+            arena_cap = hdr->used_words + 1024;
+            ctx->arena_words_per_pair = std::max<uint64_t>(ctx->arena_words_per_pair, arena_cap / np + 1);
+            continue;
+        }
+        arena_used = hdr->used_words;
+        outs.assign((const PairOut *)(h + result_out_off()), (const PairOut *)(h + result_out_off()) + np);
+        arena_copy.assign((const uint32_t *)(h + a_off), (const uint32_t *)(h + a_off) + arena_used);
+        for (auto &o : outs) o.flags &= ~SWMI_F_ARENA_OVF;
+        return SWMI_OK;
+    }
+}
+
+// records of one chunk -> per-pair lists (tmp, keyed by position in `work`)
+struct ParsedRec { uint32_t wpos; HostAln a; };
+
+static int parse_records(const std::vector<uint32_t> &arena, uint64_t used, size_t lo,
+                         std::vector<uint32_t> &ops, std::vector<ParsedRec> &recs) {
+    uint64_t at = 0;
+    while (at < used) {
+        if (at + SWMI_ALNREC_WORDS > used) return fail(SWMI_ERR_HIP, "truncated record in arena");
+        const uint32_t *w = arena.data() + at;
+        ParsedRec r;
+        r.wpos = (uint32_t)(lo + w[0]);
+        r.a.rank = w[1];
+        r.a.begin = (int32_t)w[2];
+        r.a.end_i = (int32_t)w[3];
+        r.a.end_j = (int32_t)w[4];
+        r.a.n_ops = w[5];
+        const uint64_t opw = ((uint64_t)r.a.n_ops + 15) / 16;
+        if (at + SWMI_ALNREC_WORDS + opw > used) return fail(SWMI_ERR_HIP, "record overruns arena");
+        r.a.ops_at = ops.size();
+        ops.insert(ops.end(), w + SWMI_ALNREC_WORDS, w + SWMI_ALNREC_WORDS + opw);
+        recs.push_back(r);
+        at += SWMI_ALNREC_WORDS + opw;
+    }
+    return SWMI_OK;
+}
+
+extern "C" int swmi_batch_run(swmi_ctx *ctx, swmi_batch *b, const swmi_params *p) {
+    if (!ctx || !b || !p) return fail(SWMI_ERR_INVALID, "null argument");
+    if (p->tie_mode != SWMI_TIE_SERIAL && p->tie_mode != SWMI_TIE_STRICT)
+        return fail(SWMI_ERR_INVALID, "unknown tie_mode %d", p->tie_mode);
+    // GetAlignment tests `align == alignTypes[0]`, then `== alignTypes[1]`, else deletion
+    // (SmithWaterman.java:388-401): with duplicate a/i/d characters the reference itself walks wrong
+    // cells; that behaviour is not reproduced.
+    if (p->types[0] == p->types[1] || p->types[0] == p->types[2] || p->types[1] == p->types[2])
+        return fail(SWMI_ERR_UNSUPPORTED, "alignTypes a/i/d must be pairwise distinct");
+    std::lock_guard<std::mutex> g(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    b->params = *p;
+    b->has_run = false;
+
+    const uint32_t n_refs = b->n_refs, n_reads = b->n_reads;
+    const uint64_t n_pairs = (uint64_t)n_refs * n_reads;
+    b->pairs.assign(n_pairs, PairRes{});
+    b->alns.clear(); b->ops.clear(); b->str_ref.clear(); b->str_read.clear();
+    b->ref_view_ready.assign(n_refs, 0);
+    b->ref_sites.assign(n_refs, {});
+    b->ref_degenerate.assign(n_refs, 0);
+    b->timing = swmi_timing{};
+
+    // pairs with an empty side never enter ScoreMatrix's loops (SmithWaterman.java:157-159): (0, [])
+    std::vector<Work> work;
+    work.reserve(n_pairs);
+    uint64_t total_cells = 0;
+    for (uint32_t r = 0; r < n_refs; r++) {
+        const uint32_t n = b->ref_desc[r].len;
+        for (uint32_t q = 0; q < n_reads; q++) {
+            const uint32_t m = b->read_desc[q].len;
+            if (m == 0 || n == 0) continue;
+            Work w;
+            w.pair = r * n_reads + q;
+            w.cells = (uint64_t)m * n;
+            w.dir_words = swmi_dir_words(m, n);
+            w.seam_words = m > 64u * SWMI_RMAX ? 2ull * (n + 1) : 0;
+            total_cells += w.cells;
+            work.push_back(w);
+        }
+    }
+    // longest first: the tail of the launch is made of short pairs
+    std::stable_sort(work.begin(), work.end(), [](const Work &a, const Work &c) { return a.cells > c.cells; });
+
+    RunState rs;
+    rs.ctx = ctx; rs.b = b;
+    hipEvent_t ev_total0 = ctx->ev[5];
+    (void)ev_total0;
+
+    std::vector<std::vector<ParsedRec>> all_recs;   // per chunk
+    std::vector<ParsedRec> recs;
+    std::vector<PairOut> outs;
+    std::vector<uint32_t> arena;
+    std::vector<size_t> ovf;                         // positions in `work` that overflowed their cell list
+    uint64_t dir_bytes = 0;
+
+    size_t lo = 0;
+    while (lo < work.size()) {
+        // chunk = as many pairs as fit the workspace cap (always at least one)
+        uint64_t words = 0;
+        size_t hi = lo;
+        while (hi < work.size() && (hi == lo || (words + work[hi].dir_words) * 4 <= ctx->max_workspace_bytes)) {
+            words += work[hi].dir_words;
+            hi++;
+        }
+        dir_bytes += words * 4;
+        uint64_t used = 0;
+        int rc = run_chunk(rs, work, lo, hi, nullptr, outs, arena, used);
+        if (rc) return rc;
+        for (size_t k = 0; k < hi - lo; k++) {
+            PairRes &pr = b->pairs[work[lo + k].pair];
+            pr.score = outs[k].score;
+            pr.flags = (outs[k].flags & SWMI_F_DEGENERATE) ? SWMI_PAIR_DEGENERATE : 0u;
+            pr.n_cells = outs[k].n_cells;
+            if (outs[k].flags & SWMI_F_CELL_OVF) ovf.push_back(lo + k);
+        }
+        if ((rc = parse_records(arena, used, lo, b->ops, recs))) return rc;
+        lo = hi;
+    }
+
+    // pairs with more tied cells than cell_cap: run them again on the GPU with exact-size lists
+    if (!ovf.empty()) {
+        std::vector<Work> w2;
+        std::vector<uint64_t> exact;
+        for (size_t pos : ovf) { w2.push_back(work[pos]); exact.push_back(b->pairs[work[pos].pair].n_cells); }
+        size_t lo2 = 0;
+        while (lo2 < w2.size()) {
+            uint64_t words = 0;
+            size_t hi2 = lo2;
+            while (hi2 < w2.size() && (hi2 == lo2 || (words + w2[hi2].dir_words) * 4 <= ctx->max_workspace_bytes)) {
+                words += w2[hi2].dir_words;
+                hi2++;
+            }
+            uint64_t used = 0;
+            int rc = run_chunk(rs, w2, lo2, hi2, &exact, outs, arena, used);
+            if (rc) return rc;
+            std::vector<ParsedRec> r2;
+            if ((rc = parse_records(arena, used, lo2, b->ops, r2))) return rc;
+            for (auto &r : r2) {
+                // translate the position in w2 back to a position in `work`
+                r.wpos = (uint32_t)ovf[r.wpos];
+                recs.push_back(r);
+            }
+            for (size_t k = 0; k < hi2 - lo2; k++)
+                if (outs[k].flags & SWMI_F_CELL_OVF)
+                    return fail(SWMI_ERR_HIP, "cell list overflowed again on the exact-size re-run");
+            lo2 = hi2;
+        }
+        b->timing.rerun_pairs = (uint32_t)ovf.size();
+    }
+
+    // group records by pair, ordered by rank (= OptAlignments order for the serial mode)
+    for (auto &r : recs) b->pairs[work[r.wpos].pair].count++;
+    uint64_t run = 0;
+    for (auto &w : work) { PairRes &pr = b->pairs[w.pair]; pr.first = run; run += pr.count; }
+    b->alns.resize(run);
+    for (auto &r : recs) {
+        PairRes &pr = b->pairs[work[r.wpos].pair];
+        if (r.a.rank >= pr.count) return fail(SWMI_ERR_HIP, "record rank %u out of range", r.a.rank);
+        b->alns[pr.first + r.a.rank] = r.a;
+    }
+    for (auto &w : work) {
+        PairRes &pr = b->pairs[w.pair];
+        if (!(pr.flags & SWMI_PAIR_DEGENERATE) && pr.count != pr.n_cells)
+            return fail(SWMI_ERR_HIP, "pair %u: %llu records for %llu max cells", w.pair,
+                        (unsigned long long)pr.count, (unsigned long long)pr.n_cells);
+        // DistributedSW.GetAlignments sorts the collected alignments by beginning (DistributedSW.java:480)
+        if (p->tie_mode == SWMI_TIE_STRICT && pr.count > 1)
+            std::stable_sort(b->alns.begin() + pr.first, b->alns.begin() + pr.first + pr.count,
+                             [](const HostAln &x, const HostAln &y) { return x.begin < y.begin; });
+    }
+    b->str_ref.assign(run, std::string());
+    b->str_read.assign(run, std::string());
+    for (uint64_t k = 0; k < run; k++) b->alns[k].str_id = -1;
+
+    b->timing.fill_ms = rs.fill_ms; b->timing.traceback_ms = rs.tb_ms; b->timing.d2h_ms = rs.d2h_ms;
+    b->timing.total_ms = rs.fill_ms + rs.tb_ms + rs.d2h_ms;
+    b->timing.fill_launches = rs.launches;
+    b->timing.cells = total_cells;
+    b->timing.dir_bytes = dir_bytes;
+    b->has_run = true;
+    return SWMI_OK;
+}
+
+extern "C" int swmi_batch_timing(const swmi_batch *b, swmi_timing *t) {
+    if (!b || !t) return fail(SWMI_ERR_INVALID, "null argument");
+    *t = b->timing;
+    return SWMI_OK;
+}
+
+extern "C" int swmi_align_batch(swmi_ctx *ctx, const swmi_params *p,
+                                const uint8_t *ref_bytes, const uint64_t *ref_off, uint32_t n_refs,
+                                const uint8_t *read_bytes, const uint64_t *read_off, uint32_t n_reads,
+                                swmi_batch **out) {
+    int rc = swmi_batch_upload(ctx, ref_bytes, ref_off, n_refs, read_bytes, read_off, n_reads, out);
+    if (rc) return rc;
+    rc = swmi_batch_run(ctx, *out, p);
+    if (rc) { swmi_batch_free(ctx, *out); *out = nullptr; }
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------
+// result accessors
+// ------------------------------------------------------------------------------------------
+extern "C" uint64_t swmi_batch_n_pairs(const swmi_batch *b) { return b ? (uint64_t)b->n_refs * b->n_reads : 0; }
+
+static int check_pair(const swmi_batch *b, uint64_t pair) {
+    if (!b) return fail(SWMI_ERR_INVALID, "batch is null");
+    if (!b->has_run) return fail(SWMI_ERR_INVALID, "batch has no results (run it first)");
+    if (pair >= (uint64_t)b->n_refs * b->n_reads) return fail(SWMI_ERR_RANGE, "pair %llu out of range", (unsigned long long)pair);
+    return SWMI_OK;
+}
+
+extern "C" int swmi_pair_score(const swmi_batch *b, uint64_t pair, int32_t *score) {
+    int rc = check_pair(b, pair);
+    if (rc) return rc;
+    if (score) *score = b->pairs[pair].score;
+    return SWMI_OK;
+}
+
+extern "C" int swmi_pair_n_alignments(const swmi_batch *b, uint64_t pair, uint64_t *n, uint32_t *flags) {
+    int rc = check_pair(b, pair);
+    if (rc) return rc;
+    if (n) *n = b->pairs[pair].n_cells;
+    if (flags) *flags = b->pairs[pair].flags;
+    return SWMI_OK;
+}
+
+// Pops the traceback "stack" into the two aligned strings (SmithWaterman.java:418-431): ops are stored
+// from the max cell backwards, so the strings are built by walking them in reverse.
+static void materialise(swmi_batch *b, uint64_t pair, HostAln &a, uint64_t slot) {
+    const uint32_t r = (uint32_t)(pair / b->n_reads), q = (uint32_t)(pair % b->n_reads);
+    const uint8_t *ref = b->ref_bytes.data() + b->ref_off[r];
+    const uint8_t *read = b->read_bytes.data() + b->read_off[q];
+    std::string &sr = b->str_ref[slot], &sq = b->str_read[slot];
+    sr.resize(a.n_ops); sq.resize(a.n_ops);
+    int64_t i = a.end_i, j = a.end_j;     // 1-based cell of the op being emitted
+    const uint32_t *ops = b->ops.data() + a.ops_at;
+    for (uint32_t t = 0; t < a.n_ops; t++) {
+        const uint32_t op = (ops[t >> 4] >> (2 * (t & 15))) & 3u;
+        const uint32_t pos = a.n_ops - 1 - t;
+        if (op == SWMI_DIR_A)      { sr[pos] = (char)ref[j - 1]; sq[pos] = (char)read[i - 1]; i--; j--; }
+        else if (op == SWMI_DIR_I) { sr[pos] = '_';              sq[pos] = (char)read[i - 1]; i--; }
+        else                       { sr[pos] = (char)ref[j - 1]; sq[pos] = '_';               j--; }
+    }
+    a.str_id = (int64_t)slot;
+}
+
+static const char EMPTY_STR[1] = {0};
+
+extern "C" int swmi_pair_alignment(swmi_batch *b, uint64_t pair, uint64_t k,
+                                   int32_t *begin, int32_t *end_i, int32_t *end_j,
+                                   const char **ref_aln, const char **read_aln, uint32_t *len) {
+    int rc = check_pair(b, pair);
+    if (rc) return rc;
+    PairRes &pr = b->pairs[pair];
+    if (k >= pr.n_cells) return fail(SWMI_ERR_RANGE, "alignment %llu out of range", (unsigned long long)k);
+    if (pr.flags & SWMI_PAIR_DEGENERATE) {
+        // every cell, row-major, traces to (0, "", "")  (SmithWaterman.java:378-380)
+        const uint32_t n = b->ref_desc[pair / b->n_reads].len;
+        if (begin) *begin = 0;
+        if (end_i) *end_i = (int32_t)(k / n) + 1;
+        if (end_j) *end_j = (int32_t)(k % n) + 1;
+        if (ref_aln) *ref_aln = EMPTY_STR;
+        if (read_aln) *read_aln = EMPTY_STR;
+        if (len) *len = 0;
+        return SWMI_OK;
+    }
+    HostAln &a = b->alns[pr.first + k];
+    if (a.str_id < 0) materialise(b, pair, a, pr.first + k);
+    if (begin) *begin = a.begin;
+    if (end_i) *end_i = a.end_i;
+    if (end_j) *end_j = a.end_j;
+    if (ref_aln) *ref_aln = b->str_ref[a.str_id].c_str();
+    if (read_aln) *read_aln = b->str_read[a.str_id].c_str();
+    if (len) *len = a.n_ops;
+    return SWMI_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// MapRef view (Distribution.java:403-436)
+// ------------------------------------------------------------------------------------------
+static int check_ref(const swmi_batch *b, uint32_t ref) {
+    if (!b) return fail(SWMI_ERR_INVALID, "batch is null");
+    if (!b->has_run) return fail(SWMI_ERR_INVALID, "batch has no results (run it first)");
+    if (ref >= b->n_refs) return fail(SWMI_ERR_RANGE, "reference %u out of range", ref);
+    return SWMI_OK;
+}
+
+extern "C" int swmi_ref_total(const swmi_batch *b, uint32_t ref, int32_t *total) {
+    int rc = check_ref(b, ref);
+    if (rc) return rc;
+    uint32_t t = 0;                                  // Java int arithmetic wraps
+    for (uint32_t q = 0; q < b->n_reads; q++) t += (uint32_t)b->pairs[(uint64_t)ref * b->n_reads + q].score;
+    if (total) *total = (int32_t)t;
+    return SWMI_OK;
+}
+
+static void build_ref_view(swmi_batch *b, uint32_t ref) {
+    if (b->ref_view_ready[ref]) return;
+    std::vector<SiteRef> &v = b->ref_sites[ref];
+    uint64_t deg = 0;
+    for (uint32_t q = 0; q < b->n_reads; q++) {
+        const uint64_t pair = (uint64_t)ref * b->n_reads + q;
+        const PairRes &pr = b->pairs[pair];
+        if (pr.flags & SWMI_PAIR_DEGENERATE) { deg += pr.n_cells; continue; }   // begin 0: sorts before every real site
+        for (uint64_t k = 0; k < pr.count; k++) v.push_back(SiteRef{pair, k, b->alns[pr.first + k].begin});
+    }
+    std::stable_sort(v.begin(), v.end(), [](const SiteRef &a, const SiteRef &c) { return a.begin < c.begin; });
+    b->ref_degenerate[ref] = deg;
+    b->ref_view_ready[ref] = 1;
+}
+
+extern "C" int swmi_ref_n_match_sites(swmi_batch *b, uint32_t ref, uint64_t *n) {
+    int rc = check_ref(b, ref);
+    if (rc) return rc;
+    build_ref_view(b, ref);
+    if (n) *n = b->ref_degenerate[ref] + b->ref_sites[ref].size();
+    return SWMI_OK;
+}
+
+extern "C" int swmi_ref_match_site(swmi_batch *b, uint32_t ref, uint64_t k, int32_t *begin,
+                                   const char **ref_aln, const char **read_aln, uint32_t *len) {
+    int rc = check_ref(b, ref);
+    if (rc) return rc;
+    build_ref_view(b, ref);
+    const uint64_t deg = b->ref_degenerate[ref];
+    if (k < deg) {
+        if (begin) *begin = 0;
+        if (ref_aln) *ref_aln = EMPTY_STR;
+        if (read_aln) *read_aln = EMPTY_STR;
+        if (len) *len = 0;
+        return SWMI_OK;
+    }
+    if (k - deg >= b->ref_sites[ref].size()) return fail(SWMI_ERR_RANGE, "match site %llu out of range", (unsigned long long)k);
+    const SiteRef &s = b->ref_sites[ref][k - deg];
+    return swmi_pair_alignment(b, s.pair, s.k, begin, nullptr, nullptr, ref_aln, read_aln, len);
+}

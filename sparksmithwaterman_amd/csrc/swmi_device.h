@@ -1,0 +1,128 @@
+// swmi_device.h -- structures shared by the host runtime (swmi_api.cpp) and the gfx950 kernels
+// (swmi_kernels.hip).  HBM data layout of one batch:
+//
+//   seqw   uint32[]   every sequence twice: a BYTE image (1 code/base, 4 per dword) and, for
+//                     pure-ACGT sequences, a PACKED image (2 bits/base, 16 per dword, base k of a
+//                     dword in bits 2k..2k+1).  Each image is followed by SWMI_SEQ_PAD_WORDS zero
+//                     dwords so a 16-step block may over-read past the end.
+//   refs / reads      SeqDesc per sequence.
+//   pairs  PairDesc[] one per (ref, read) pair of the launch (any order; the host sorts by work).
+//   dir    uint32[]   direction field, 2 bits per DP cell.  For one pair and one strip of 64*R
+//                     read rows it is laid out [w][k][lane]: dword ((w*R + k)*64 + lane) holds the
+//                     16 anti-diagonal steps t = 16w .. 16w+15 of row i = strip*64R + lane*R + k + 1,
+//                     step t at bits 2*(15 - t%16) (+1), where lane `lane` is at column j = t - lane + 1.
+//                     Every store instruction therefore writes 256 contiguous bytes.
+//   cells  uint2[]    per pair, up to cell_cap (i, j) coordinates of the tied maximum cells.
+//   out    PairOut[]  per pair score / count / flags.
+//   arena  uint32[]   variable-length alignment records appended by the traceback kernel.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define SWMI_HD __host__ __device__
+#else
+#define SWMI_HD
+#endif
+
+#define SWMI_SEQ_PAD_WORDS 24u
+#define SWMI_NO_PACKED     0xFFFFFFFFu
+#define SWMI_RMAX          4          // rows per lane in the widest kernel variant
+#define SWMI_CODE_PAD      0x1FFu     // never equals a base code (codes are 0..255)
+
+// direction codes stored in the field (2 bits): bit1 = alignment chosen, bit0 = insertion chosen
+#define SWMI_DIR_D 0u
+#define SWMI_DIR_I 1u
+#define SWMI_DIR_A 2u   // 2 or 3
+
+// PairOut.flags
+#define SWMI_F_DEGENERATE   0x1u   // max score 0: all m*n cells tie (no alignment records emitted)
+#define SWMI_F_CELL_OVF     0x2u   // more tied max cells than cell_cap: host re-runs the pair
+#define SWMI_F_ARENA_OVF    0x4u   // a record of this pair did not fit the arena: host grows it, re-runs
+
+struct SeqDesc {
+    uint32_t len;     // bases
+    uint32_t boff;    // dword offset of the byte image in seqw
+    uint32_t poff;    // dword offset of the packed image, SWMI_NO_PACKED if the sequence is not pure ACGT
+    uint32_t pad;
+};
+
+struct PairDesc {
+    uint32_t ref_id;
+    uint32_t read_id;
+    uint32_t out_id;      // index into out[] / cells[] (the pair's position in the batch)
+    uint32_t pad;
+    uint64_t dir_off;     // dword offset of this pair's direction field in dir[]
+    uint64_t seam_off;    // dword offset of the 2*(n+1) int32 strip-seam rows (multi-strip pairs only)
+};
+
+struct PairOut {
+    int32_t  score;
+    uint32_t flags;
+    uint64_t n_cells;     // number of tied maximum cells (m*n when degenerate)
+};
+
+// header of one alignment record in the arena (followed by ceil(n_ops/16) dwords of 2-bit ops,
+// op t of the traceback (first = the max cell) at bits 2*(t%16) of dword t/16)
+struct AlnRec {
+    uint32_t out_id;
+    uint32_t rank;        // position of the alignment in OptAlignments order
+    int32_t  begin;       // GetAlignment's `beginning` (SmithWaterman.java:378-383)
+    int32_t  end_i, end_j;
+    uint32_t n_ops;
+};
+#define SWMI_ALNREC_WORDS 6u
+
+struct ArenaHdr {
+    unsigned long long used_words;   // bump pointer (may exceed capacity: records past it are dropped)
+    unsigned long long n_records;
+};
+
+struct FillArgs {
+    const uint32_t *seqw;
+    const SeqDesc  *refs;
+    const SeqDesc  *reads;
+    const PairDesc *pairs;
+    uint32_t       *dir;
+    int32_t        *seam;
+    PairOut        *out;
+    uint2          *cells;
+    const uint64_t *cells_off;   // per out_id offset into cells[] (null: out_id * cell_cap)
+    const uint32_t *cells_cap;   // per out_id capacity        (null: cell_cap)
+    uint32_t        n_pairs;
+    uint32_t        cell_cap;
+    int32_t         match, mismatch, gap;
+    uint32_t        strict;      // tie mode
+};
+
+struct TraceArgs {
+    const uint32_t *seqw;
+    const SeqDesc  *refs;
+    const SeqDesc  *reads;
+    const PairDesc *pairs;
+    const uint32_t *dir;
+    PairOut        *out;
+    const uint2    *cells;
+    const uint64_t *cells_off;
+    const uint32_t *cells_cap;
+    ArenaHdr       *hdr;
+    uint32_t       *arena;
+    uint64_t        arena_cap_words;
+    uint32_t        n_pairs;
+    uint32_t        cell_cap;
+    int32_t         match, mismatch, gap;
+    uint32_t        strict;
+    uint32_t        lds_words;   // staging words per block for the ops of one alignment
+};
+
+// rows per lane for a read of m bases
+SWMI_HD static inline uint32_t swmi_rows_per_lane(uint32_t m) {
+    uint32_t r = (m + 63u) / 64u;
+    return r < 1u ? 1u : (r > SWMI_RMAX ? SWMI_RMAX : r);
+}
+// dwords of direction field for one pair
+SWMI_HD static inline uint64_t swmi_dir_words(uint32_t m, uint32_t n) {
+    uint32_t R = swmi_rows_per_lane(m);
+    uint64_t strips = ((uint64_t)m + 64u * R - 1u) / (64u * R);
+    uint64_t wblocks = ((uint64_t)n + 63u + 15u) / 16u;   // T = n + 63 steps at most
+    return strips * wblocks * R * 64u;
+}

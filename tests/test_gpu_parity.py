@@ -1,0 +1,168 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle, bit-exact.
+
+Scores are Java ints and alignments are strings: equality is exact, no tolerance anywhere.
+The oracle itself is "parity unpinned" (the reference ships no fixtures and there is no JVM to run it);
+see oracle/sw_oracle.c.
+"""
+import random
+
+import pytest
+
+import sparksmithwaterman_amd as sw
+from sparksmithwaterman_amd import synth
+from oracle import sw_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+REF = "CCTGGGTCCTGCCTCGCATCTGACCAGGGCAGGTGGCCTCCTCATCACACTGCTGCCTCTGCTGTTGGCCCTGCTCATGA"   # EngineerData.java:23
+READ_80 = "AATTTTAGTCTCTCCCTACCCTTTTGGACAGAGCTTCCTGTCCTCTCATTTCACAGGTTATGCAACAGAGGGTTCTGTGT"  # EngineerData.java:26
+READ_20 = "ACTGACTGACTGACTGACTG"   # EngineerData.java:29
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = sw.Context(0)
+    yield c
+    c.close()
+
+
+def _types(t):
+    return b"".join(x.encode() for x in t) if not isinstance(t, bytes) else t
+
+
+def check_batch(ctx, refs, reads, scores=(5, -3, -4), types=("a", "i", "d", "-"), tie=0, cells=True):
+    b = ctx.upload(refs, reads).run(sw.make_params(scores, types, tie))
+    try:
+        for r, ref in enumerate(refs):
+            for q, read in enumerate(reads):
+                pair = r * len(reads) + q
+                es, ea = orc.opt_alignments((ref, read), scores, _types(types), tie, with_cells=cells and tie == 0)
+                assert b.score(pair) == es, (r, q)
+                n, flags = b.n_alignments(pair)
+                assert n == len(ea), (r, q, n, len(ea))
+                if flags & sw.PAIR_DEGENERATE:
+                    assert es == 0 and all(a[:2] == (0, ("", "")) for a in ea)
+                    if n:
+                        assert b.alignment(pair, 0) == (0, ("", ""))
+                        assert b.alignment(pair, n - 1, True) == (0, ("", ""), (len(read), len(ref)))
+                    continue
+                got = b.alignments(pair, with_cell=cells and tie == 0)
+                assert got == ea, (r, q, ref, read, scores, tie)
+            t, (_, sites) = orc.map_ref((">gi|r%d" % r, ref), reads, scores, _types(types), tie)
+            assert b.ref_total(r) == t
+            if not any(b.n_alignments(r * len(reads) + q)[1] & sw.PAIR_DEGENERATE and
+                       b.n_alignments(r * len(reads) + q)[0] > 5000 for q in range(len(reads))):
+                assert b.ref_match_sites(r) == sites
+    finally:
+        b.free()
+
+
+def test_kats(ctx, kats):
+    for k in kats:
+        b = ctx.upload([k["ref"]], [k["read"]]).run(sw.make_params(k["scores"], ("a", "i", "d", "-"), k["tie_mode"]))
+        assert b.score(0) == k["score"], k["name"]
+        assert [[x[0], x[1][0], x[1][1]] for x in b.alignments(0)] == k["alignments"], k["name"]
+        if "map_ref_sorted" in k:
+            assert [[x[0], x[1][0], x[1][1]] for x in b.ref_match_sites(0)] == k["map_ref_sorted"]
+        b.free()
+
+
+def test_mirror_classes_match_reference_call_shapes(ctx):
+    score, alns = sw.SmithWaterman.OptAlignments(ctx).call(["ACGT", "CG"], [5, -3, -4], ["a", "i", "d", "-"])
+    assert (score, alns) == (10, [(2, ("CG", "CG"))])
+    score, alns = sw.DistributedSW.OptAlignments(ctx).call(["AAAA", "AACA"], [1, -1, -1], ["a", "i", "d", "-"])
+    assert score == 2 and alns[3] == (2, ("AA_A", "AACA"))
+    ref = (">gi|ref0", REF * 2)
+    reads = [READ_20, REF[5:35], READ_80[:30], ""]
+    algo = ([5, -3, -4], ["a", "i", "d", "-"])
+    total, (ref_out, sites) = sw.Distribution.MapRef(ctx).call((ref, reads, algo))
+    et, (_, es) = orc.map_ref(ref, reads)
+    assert ref_out is ref and total == et and sites == es
+    tuples = sw.Distribution.CombineReadsToRef().call([ref, (">gi|ref1", REF[::-1])], reads, algo)
+    res = sw.Distribution.MapPartition(ctx).call(tuples)
+    assert [r[0] for r in res] == [orc.map_ref(t[0], reads)[0] for t in tuples]
+    red = sw.Distribution.ReduceMax()
+    for t, v in res:
+        red.add(t, v)
+    assert red.result()[0] == max(r[0] for r in res)
+
+
+@pytest.mark.parametrize("tie", [0, 1])
+def test_random_small_alphabets_many_ties(ctx, tie):
+    rng = random.Random(99 + tie)
+    for trial in range(12):
+        alpha = rng.choice(["AC", "ACGT", "ACGTN", "acgtACGT", "AX-"])
+        refs = ["".join(rng.choice(alpha) for _ in range(rng.randint(1, 70))) for _ in range(6)]
+        reads = ["".join(rng.choice(alpha) for _ in range(rng.randint(2 if tie else 1, 40))) for _ in range(5)]
+        sc = rng.choice([(5, -3, -4), (1, -1, -1), (2, -1, -2), (1, 0, 0), (3, -2, 0), (2, -3, -1)])
+        check_batch(ctx, refs, reads, sc, tie=tie)
+
+
+def test_read_lengths_across_row_classes(ctx):
+    # rows per lane R = 1,2,3,4 and the multi-strip path (m > 256), ragged reference lengths
+    rng = random.Random(5)
+    reads = ["".join(rng.choice("ACGT") for _ in range(m)) for m in (1, 63, 64, 65, 128, 129, 150, 192, 193, 256, 257, 300, 520)]
+    refs = ["".join(rng.choice("ACGT") for _ in range(n)) for n in (1, 15, 16, 17, 100, 333)]
+    refs.append(reads[6][10:120] + "ACGTTGCA" * 10)
+    check_batch(ctx, refs, reads)
+
+
+def test_empty_and_degenerate(ctx):
+    check_batch(ctx, ["CCCC", "", "ACGT", "GGGGGGGGGG"], ["AA", "", "CG"])
+    check_batch(ctx, ["CCCCCCCCCCCCCCCCCCCCCCCCCCCCCC" * 4], ["A" * 70])
+
+
+def test_non_acgt_and_case(ctx):
+    check_batch(ctx, ["acgtNNNNacgtRYKM", "ACGTNNNNACGTRYKM", "nnnn\xe9\xc9"], ["ACGTNNNN", "acgtnnnnacgt", "N\xe9\xc9n"])
+
+
+def test_engineerdata_periodic_overflowing_cell_list(ctx):
+    # EngineerData.java:118 repeats REF: every period is a tied maximum. 100 periods > cell_cap (64)
+    check_batch(ctx, [REF * 100, REF * 3], [REF[10:50], READ_20, READ_80])
+    ctx.set_option("cell_cap", 4)
+    try:
+        check_batch(ctx, [REF * 9], [REF[10:50], READ_20])
+    finally:
+        ctx.set_option("cell_cap", 64)
+
+
+def test_arena_growth(ctx):
+    ctx.set_option("arena_words_per_pair", 1)
+    try:
+        rng = random.Random(17)
+        refs = ["".join(rng.choice("ACGT") for _ in range(400)) for _ in range(40)]
+        check_batch(ctx, refs, [refs[3][50:200]])
+    finally:
+        ctx.set_option("arena_words_per_pair", 48)
+
+
+def test_unusual_scores_generic_path(ctx):
+    rng = random.Random(3)
+    refs = ["".join(rng.choice("ACGT") for _ in range(90)) for _ in range(4)]
+    reads = ["".join(rng.choice("ACGT") for _ in range(33)) for _ in range(3)]
+    check_batch(ctx, refs, reads, (300, -200, -150))       # scores outside int8: compare path, not the profile
+    check_batch(ctx, refs, reads, (2, 1, 1), cells=True)   # positive mismatch / gap
+
+
+def test_duplicate_align_types_rejected(ctx):
+    with pytest.raises(sw.SwmiError) as e:
+        ctx.upload(["ACGT"], ["CG"]).run(sw.make_params((5, -3, -4), ("a", "a", "d", "-")))
+    assert e.value.code == -5
+
+
+def test_config1_headline_batch_scores_and_winner(ctx):
+    refs, reads = synth.config_1k()
+    b = ctx.upload(refs, reads).run()
+    rng = random.Random(1)
+    sample = [0] + rng.sample(range(1, len(refs)), 24)
+    for r in sample:
+        es, ea = orc.opt_alignments((refs[r], reads[0]))
+        assert b.score(r) == es
+        assert b.alignments(r) == ea
+    totals = [b.ref_total(r) for r in range(len(refs))]
+    assert max(range(len(refs)), key=lambda r: totals[r]) == 0      # the read was cut from reference 0
+    # checksum of all scores against the oracle's multi-threaded pass over the same batch
+    ob = orc.bench(refs, reads, nthreads=8)
+    assert sum(totals) == ob["sum_score"]
+    assert sum(b.n_alignments(r)[0] for r in range(len(refs))) == ob["sum_aln"]
+    b.free()

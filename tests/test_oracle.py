@@ -100,3 +100,12 @@ def test_bench_leg_counts_cells():
     r = orc.bench([REF * 2, REF], [READ_20, READ_80], nthreads=2)
     assert r["cells"] == (160 + 80) * (20 + 80)
     assert r["seconds"] > 0
+
+
+def test_latin1_uppercase_rule():
+    # Character.toUpperCase: e-acute (0xE9) -> E-acute (0xC9); the division sign 0xF7 and y-diaeresis 0xFF stay apart
+    assert orc.opt_alignments(("\xe9", "\xc9"))[0] == 5
+    assert orc.opt_alignments(("\xf7", "\xd7"))[0] == 0
+    assert orc.opt_alignments(("\xff", "\xdf"))[0] == 0
+    assert opy.opt_alignments(("\xe9", "\xc9"))[0] == 5
+    assert opy.opt_alignments(("\xf7", "\xd7"))[0] == 0
