@@ -172,7 +172,7 @@ __device__ __forceinline__ void fill_pair(const FillArgs &A, const PairDesc pd, 
                 const int nin = wave_shr1(topn, hb);
                 c0 += 1;
                 const bool active = (uint32_t)c0 < n;
-                uint64_t evmask = 0;
+                int mrow = -1;                 // stays -1 in lanes that are off their column range
                 if (active) {
                     int diag = nprev, up = nin;
 #pragma unroll
@@ -193,16 +193,16 @@ __device__ __forceinline__ void fill_pair(const FillArgs &A, const PairDesc pd, 
                         h[k] = hv;
                     }
                     hb = h[R - 1];
-                    int mrow = h[0];
+                    mrow = h[0];
 #pragma unroll
                     for (int k = 1; k < R; ++k) mrow = mrow > h[k] ? mrow : h[k];
-                    evmask = __ballot(mrow >= thr);
                     if (feeds_seam && lane == WAVE - 1) seam_out[c0 + 1] = hb;
                 }
                 nprev = nin;
 
                 // ---- rare: some lane reached the running maximum ---------------------------------
-                if (__builtin_expect(evmask != 0, 0)) {
+                // all 64 lanes vote, so thr/cnt below stay wave-uniform
+                if (__builtin_expect(__ballot(mrow >= thr) != 0, 0)) {
                     int cand = -1;
 #pragma unroll
                     for (int k = 0; k < R; ++k)
