@@ -247,16 +247,45 @@ void sw_oracle_free(sw_oracle_result *r) {
     free(r->aln); free(r->H); free(r->T); free(r);
 }
 
+/* Matrix storage a caller may lend to sw_oracle_align_buf so that a worker thread does not go
+ * through mmap/munmap for every pair (the JVM's allocator does not either). */
+typedef struct { int32_t *H; char *T; size_t cap; } sw_oracle_scratch;
+
+static sw_oracle_result *align_impl(const unsigned char *ref, int64_t n,
+                                    const unsigned char *read, int64_t m,
+                                    const int32_t scores[3], const char types[4],
+                                    int tie_mode, int keep_matrices, sw_oracle_scratch *sc);
+
 /* SmithWaterman.java:62-92 (tie_mode 0) / DistributedSW.java:77-104 (tie_mode 1). */
 sw_oracle_result *sw_oracle_align(const unsigned char *ref, int64_t n,
                                   const unsigned char *read, int64_t m,
                                   const int32_t scores[3], const char types[4],
                                   int tie_mode, int keep_matrices) {
+    return align_impl(ref, n, read, m, scores, types, tie_mode, keep_matrices, NULL);
+}
+
+static sw_oracle_result *align_impl(const unsigned char *ref, int64_t n,
+                                    const unsigned char *read, int64_t m,
+                                    const int32_t scores[3], const char types[4],
+                                    int tie_mode, int keep_matrices, sw_oracle_scratch *sc) {
     sw_oracle_result *r = (sw_oracle_result *)calloc(1, sizeof(*r));
     if (!r) return NULL;
     size_t cells = (size_t)(m + 1) * (size_t)(n + 1);
-    int32_t *H = (int32_t *)malloc(cells * sizeof(int32_t));
-    char *T = (char *)malloc(cells);
+    int32_t *H;
+    char *T;
+    if (sc) {
+        if (sc->cap < cells) {
+            free(sc->H); free(sc->T);
+            sc->H = (int32_t *)malloc(cells * sizeof(int32_t));
+            sc->T = (char *)malloc(cells);
+            sc->cap = (sc->H && sc->T) ? cells : 0;
+        }
+        H = sc->H; T = sc->T;
+        keep_matrices = 0;
+    } else {
+        H = (int32_t *)malloc(cells * sizeof(int32_t));
+        T = (char *)malloc(cells);
+    }
     cell_list mc = { 0, 0, 0 };
     if (!H || !T) goto fail;
     int rc = (tie_mode == SW_TIE_STRICT)
@@ -271,10 +300,11 @@ sw_oracle_result *sw_oracle_align(const unsigned char *ref, int64_t n,
     if (tie_mode == SW_TIE_STRICT) stable_sort_by_begin(r->aln, r->n_aln);   /* DistributedSW:480 */
     free(mc.v);
     r->m = m; r->n = n;
-    if (keep_matrices) { r->H = H; r->T = T; } else { free(H); free(T); }
+    if (keep_matrices) { r->H = H; r->T = T; } else if (!sc) { free(H); free(T); }
     return r;
 fail:
-    free(mc.v); free(H); free(T);
+    free(mc.v);
+    if (!sc) { free(H); free(T); }
     if (r) { r->H = NULL; r->T = NULL; sw_oracle_free(r); }
     return NULL;
 }
@@ -339,6 +369,7 @@ typedef struct {
 static void *bench_worker(void *p) {
     bench_job *b = (bench_job *)p;
     int64_t ls = 0, la = 0, lc = 0;
+    sw_oracle_scratch scr = { NULL, NULL, 0 };
     for (;;) {
         pthread_mutex_lock(&b->mu);
         int64_t t = b->next++;
@@ -346,11 +377,12 @@ static void *bench_worker(void *p) {
         if (t >= b->n_refs * b->n_reads) break;
         int64_t r = t / b->n_reads, q = t % b->n_reads;
         int64_t n = b->ref_off[r + 1] - b->ref_off[r], m = b->read_off[q + 1] - b->read_off[q];
-        sw_oracle_result *res = sw_oracle_align(b->refs + b->ref_off[r], n,
-                                                b->reads + b->read_off[q], m,
-                                                b->scores, b->types, b->tie_mode, 0);
+        sw_oracle_result *res = align_impl(b->refs + b->ref_off[r], n,
+                                           b->reads + b->read_off[q], m,
+                                           b->scores, b->types, b->tie_mode, 0, &scr);
         if (res) { ls += res->score; la += res->n_aln; lc += m * n; sw_oracle_free(res); }
     }
+    free(scr.H); free(scr.T);
     pthread_mutex_lock(&b->mu);
     b->sum_score += ls; b->sum_aln += la; b->cells += lc;
     pthread_mutex_unlock(&b->mu);

@@ -1,0 +1,60 @@
+"""The N>1 exchange step on CPU: world_size-2 gloo processes running the same reduce code bench.py uses."""
+import os
+import socket
+
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from sparksmithwaterman_amd import distributed as swd
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    totals_all = [10, 694, 237, 694, 0, 5, 694, 300]      # 8 references, three tied winners
+    lo, hi = swd.shard_bounds(len(totals_all), rank, world)
+    best, winners = swd.global_max_with_ties(totals_all[lo:hi], range(lo, hi))
+    topk = swd.global_top_k(totals_all[lo:hi], range(lo, hi), 4)
+    neg = swd.global_max_with_ties([-3, -1], [lo, lo + 1])     # `int max = 0`: negative totals never win
+    q.put((rank, best, winners, topk, neg))
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_reduce():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=120) for _ in ps]
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, best, winners, topk, neg in res:
+        assert best == 694 and winners == [1, 3, 6]
+        assert topk == [(694, 1), (694, 3), (694, 6), (300, 7)]
+        assert neg == (0, [])
+
+
+def test_shard_bounds_cover_everything():
+    for n in (0, 1, 7, 1000, 1001):
+        for w in (1, 2, 3, 8):
+            spans = [swd.shard_bounds(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+            assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def test_single_process_reduce_without_init():
+    assert swd.global_max_with_ties([1, 9, 9], [10, 11, 12]) == (9, [11, 12])
+    assert swd.global_top_k([1, 9, 9], [10, 11, 12], 2) == [(9, 11), (9, 12)]
