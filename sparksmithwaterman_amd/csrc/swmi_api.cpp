@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -120,12 +121,13 @@ struct swmi_batch {
     std::vector<uint64_t> ref_off, read_off;
     std::vector<SeqDesc> ref_desc, read_desc;
     // device
-    DevBuf d_seqw, d_refs, d_reads, d_pairs, d_dir, d_seam, d_result, d_cells, d_cells_off, d_cells_cap;
+    DevBuf d_seqw, d_refs, d_reads, d_pairs, d_dir, d_seam, d_result, d_cells, d_cells_off, d_cells_cap, d_dbg, d_dbg2;
     PinnedBuf h_result;
     // per run
     swmi_params params{};
     bool has_run = false;
-    std::vector<uint32_t> order;            // sorted position -> pair index (ref * n_reads + read)
+    std::vector<uint8_t> pairs_on_device;   // image of the PairDesc array currently in d_pairs
+    const void *pairs_dev_ptr = nullptr;
     std::vector<PairRes> pairs;             // by pair index
     std::vector<HostAln> alns;              // grouped by pair, ordered as OptAlignments returns them
     std::vector<uint32_t> ops;              // concatenated op words of all records
@@ -222,7 +224,8 @@ extern "C" int swmi_set_option(swmi_ctx *ctx, const char *name, int64_t value) {
 // ------------------------------------------------------------------------------------------
 // Canonical base codes: Character.toUpperCase restricted to ISO-8859-1 input (SmithWaterman.java:311-312:
 // a-z and 0xE0-0xFE except 0xF7 drop 0x20; 0xB5 and 0xFF map outside Latin-1 and only equal themselves) followed by a permutation of the byte values that puts A,C,G,T on
-// 0..3, so that code(x) == code(y)  <=>  toUpperCase(x) == toUpperCase(y).
+// the codes 0,8,16,24 (their bit offsets in a 4 x int8 score profile), so that
+// code(x) == code(y)  <=>  toUpperCase(x) == toUpperCase(y).
 static const uint8_t *code_table() {
     static uint8_t T[256];
     static bool init = false;
@@ -230,7 +233,7 @@ static const uint8_t *code_table() {
         uint8_t perm[256];
         for (int i = 0; i < 256; i++) perm[i] = (uint8_t)i;
         const uint8_t acgt[4] = {'A', 'C', 'G', 'T'};
-        for (int k = 0; k < 4; k++) std::swap(perm[acgt[k]], perm[k]);
+        for (int k = 0; k < 4; k++) std::swap(perm[acgt[k]], perm[8 * k]);   // A,C,G,T -> 0,8,16,24
         for (int i = 0; i < 256; i++) {
             int u = i;
             if ((i >= 'a' && i <= 'z') || (i >= 0xE0 && i <= 0xFE && i != 0xF7)) u = i - 32;
@@ -250,6 +253,7 @@ static void encode_sequences(const uint8_t *bytes, const uint64_t *off, uint32_t
         const uint8_t *p = bytes + off[s];
         SeqDesc d{};
         d.len = (uint32_t)len;
+        seqw.resize((seqw.size() + 3) & ~(size_t)3, 0u);          // 16-byte aligned image (dwordx4 loads)
         d.boff = (uint32_t)seqw.size();
         const size_t bw = (len + 3) / 4;
         seqw.resize(seqw.size() + bw + SWMI_SEQ_PAD_WORDS, 0u);
@@ -257,17 +261,10 @@ static void encode_sequences(const uint8_t *bytes, const uint64_t *off, uint32_t
         uint32_t *bwp = seqw.data() + d.boff;
         for (uint64_t k = 0; k < len; k++) {
             const uint32_t c = T[p[k]];
-            acgt &= c < 4;
+            acgt &= (c & 0xE7u) == 0;                               // 0, 8, 16 or 24
             bwp[k >> 2] |= c << (8 * (k & 3));
         }
-        d.poff = SWMI_NO_PACKED;
-        if (acgt) {
-            d.poff = (uint32_t)seqw.size();
-            const size_t pw = (len + 15) / 16;
-            seqw.resize(seqw.size() + pw + SWMI_SEQ_PAD_WORDS, 0u);
-            uint32_t *pp = seqw.data() + d.poff;
-            for (uint64_t k = 0; k < len; k++) pp[k >> 4] |= (uint32_t)T[p[k]] << (2 * (k & 15));
-        }
+        d.acgt = acgt ? 1u : 0u;
         desc[s] = d;
     }
 }
@@ -291,7 +288,7 @@ extern "C" void swmi_batch_free(swmi_ctx *ctx, swmi_batch *b) {
     if (ctx) (void)hipSetDevice(ctx->device);
     b->d_seqw.release(); b->d_refs.release(); b->d_reads.release(); b->d_pairs.release();
     b->d_dir.release(); b->d_seam.release(); b->d_result.release(); b->d_cells.release();
-    b->d_cells_off.release(); b->d_cells_cap.release();
+    b->d_cells_off.release(); b->d_cells_cap.release(); b->d_dbg.release(); b->d_dbg2.release();
     b->h_result.release();
     delete b;
 }
@@ -382,7 +379,7 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
     // pair descriptors, direction-field and seam offsets
     std::vector<PairDesc> pd(np);
     uint64_t dir_words = 0, seam_words = 0;
-    uint32_t max_path = 0;
+    uint32_t max_path = 0, max_read = 0;
     for (size_t k = 0; k < np; k++) {
         const Work &w = work[lo + k];
         PairDesc d{};
@@ -395,11 +392,19 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
         seam_words += w.seam_words;
         pd[k] = d;
         max_path = std::max(max_path, b->ref_desc[d.ref_id].len + b->read_desc[d.read_id].len);
+        max_read = std::max(max_read, b->read_desc[d.read_id].len);
     }
     if ((rc = b->d_pairs.reserve(np * sizeof(PairDesc)))) return rc;
     if ((rc = b->d_dir.reserve(std::max<uint64_t>(dir_words, 1) * 4))) return rc;
     if ((rc = b->d_seam.reserve(std::max<uint64_t>(seam_words, 1) * 4))) return rc;
-    HIP_TRY(hipMemcpyAsync(b->d_pairs.p, pd.data(), np * sizeof(PairDesc), hipMemcpyHostToDevice, ctx->stream));
+    // repeated runs of one batch schedule the same pairs: skip the H2D copy when nothing changed
+    if (b->pairs_dev_ptr != b->d_pairs.p || b->pairs_on_device.size() != np * sizeof(PairDesc) ||
+        memcmp(b->pairs_on_device.data(), pd.data(), np * sizeof(PairDesc)) != 0) {
+        HIP_TRY(hipMemcpyAsync(b->d_pairs.p, pd.data(), np * sizeof(PairDesc), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));      // pd is a local: the copy must be done before it dies
+        b->pairs_on_device.assign((const uint8_t *)pd.data(), (const uint8_t *)pd.data() + np * sizeof(PairDesc));
+        b->pairs_dev_ptr = b->d_pairs.p;
+    }
     if (seam_words) HIP_TRY(hipMemsetAsync(b->d_seam.p, 0, seam_words * 4, ctx->stream));
 
     // cell lists
@@ -422,9 +427,10 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
     }
     if ((rc = b->d_cells.reserve(std::max<uint64_t>(cells_total, 1) * sizeof(uint2)))) return rc;
 
-    const uint32_t lds_words = (max_path + 15) / 16 + 1;
-    if (lds_words * 4ull > 160 * 1024)
-        return fail(SWMI_ERR_UNSUPPORTED, "alignment path of up to %u ops does not fit the LDS staging buffer", max_path);
+    const uint32_t lds_words = (max_path + 3) / 4 + 1;        // one staged op per byte
+    const uint32_t lds_read_words = (max_read + 3) / 4 + 1;
+    if ((lds_words + lds_read_words) * 4ull > 128 * 1024)
+        return fail(SWMI_ERR_UNSUPPORTED, "a pair of %u bases in total does not fit the traceback's LDS staging", max_path);
 
     uint64_t arena_cap = std::max<uint64_t>(np * ctx->arena_words_per_pair, 1024);
     std::vector<uint8_t> saved_outs;       // PairOut block carried across an arena re-allocation
@@ -432,10 +438,11 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
         const size_t a_off = result_arena_off(np);
         if ((rc = b->d_result.reserve(a_off + arena_cap * 4))) return rc;
         uint8_t *res = b->d_result.as<uint8_t>();
-        HIP_TRY(hipMemsetAsync(res, 0, 64, ctx->stream));
-        if (attempt > 0)
+        if (attempt > 0) {         // (on the first attempt the fill kernel zeroes the arena header itself)
+            HIP_TRY(hipMemsetAsync(res, 0, 64, ctx->stream));
             HIP_TRY(hipMemcpyAsync(res + result_out_off(), saved_outs.data(), saved_outs.size(),
                                    hipMemcpyHostToDevice, ctx->stream));
+        }
 
         FillArgs &fa = rs.fa;
         fa.seqw = b->d_seqw.as<uint32_t>();
@@ -448,6 +455,13 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
         fa.cells = b->d_cells.as<uint2>();
         fa.cells_off = cells_exact ? b->d_cells_off.as<uint64_t>() : nullptr;
         fa.cells_cap = cells_exact ? b->d_cells_cap.as<uint32_t>() : nullptr;
+        fa.hdr = (ArenaHdr *)res;
+        fa.dbg = nullptr;
+        if (getenv("SWMI_DEBUG_FILL")) {        // diagnostics: per-pair slow-path entries and wave cycles
+            if ((rc = b->d_dbg.reserve(np * 16))) return rc;
+            fa.dbg = b->d_dbg.as<unsigned long long>();
+            fa.dbg_thr0 = getenv("SWMI_DEBUG_THR0") ? (uint32_t)atoi(getenv("SWMI_DEBUG_THR0")) : 1u;
+        }
         fa.n_pairs = (uint32_t)np;
         fa.cell_cap = ctx->cell_cap;
         fa.match = b->params.match; fa.mismatch = b->params.mismatch; fa.gap = b->params.gap;
@@ -463,6 +477,13 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
         ta.n_pairs = fa.n_pairs; ta.cell_cap = fa.cell_cap;
         ta.match = fa.match; ta.mismatch = fa.mismatch; ta.gap = fa.gap; ta.strict = fa.strict;
         ta.lds_words = lds_words;
+        ta.lds_read_words = lds_read_words;
+        ta.dbg = nullptr;
+        if (getenv("SWMI_DEBUG_FILL")) {
+            if ((rc = b->d_dbg2.reserve(np * 32))) return rc;
+            HIP_TRY(hipMemsetAsync(b->d_dbg2.p, 0, np * 32, ctx->stream));
+            ta.dbg = b->d_dbg2.as<unsigned long long>();
+        }
 
         if (attempt == 0) {       // the direction field survives an arena-overflow retry
             if (ctx->profiling) HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
@@ -485,6 +506,25 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
             if (attempt == 0) { HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1])); rs.fill_ms += ms; }
             HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3])); rs.tb_ms += ms;
             HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4])); rs.d2h_ms += ms;
+        }
+        if (ta.dbg) {
+            std::vector<unsigned long long> d(np * 4);
+            HIP_TRY(hipMemcpy(d.data(), ta.dbg, np * 32, hipMemcpyDeviceToHost));
+            double a0 = 0, a1 = 0, a2 = 0, a3 = 0; unsigned long long mx = 0;
+            for (size_t k = 0; k < np; k++) { a0 += d[4*k]; a1 += d[4*k+1]; a2 += d[4*k+2]; a3 += d[4*k+3]; mx = std::max(mx, d[4*k]); }
+            fprintf(stderr, "[swmi tb dbg] wave ticks mean=%.0f max=%llu; walk ticks mean=%.0f; steps mean=%.1f; iterations mean=%.2f\n",
+                    a0 / np, mx, a1 / np, a2 / np, a3 / np);
+        }
+        if (fa.dbg && attempt == 0) {
+            std::vector<unsigned long long> d(np * 2);
+            HIP_TRY(hipMemcpy(d.data(), fa.dbg, np * 16, hipMemcpyDeviceToHost));
+            unsigned long long ev = 0, cyc = 0, evmax = 0, cmax = 0, cmin = ~0ull;
+            for (size_t k = 0; k < np; k++) {
+                ev += d[2 * k]; cyc += d[2 * k + 1];
+                evmax = std::max(evmax, d[2 * k]); cmax = std::max(cmax, d[2 * k + 1]); cmin = std::min(cmin, d[2 * k + 1]);
+            }
+            fprintf(stderr, "[swmi fill dbg] pairs=%zu slow-path entries mean=%.1f max=%llu; wave ticks mean=%.0f min=%llu max=%llu\n",
+                    np, (double)ev / np, evmax, (double)cyc / np, cmin, cmax);
         }
         const uint8_t *h = (const uint8_t *)b->h_result.p;
         const ArenaHdr *hdr = (const ArenaHdr *)h;

@@ -1,16 +1,19 @@
 // swmi_device.h -- structures shared by the host runtime (swmi_api.cpp) and the gfx950 kernels
 // (swmi_kernels.hip).  HBM data layout of one batch:
 //
-//   seqw   uint32[]   every sequence twice: a BYTE image (1 code/base, 4 per dword) and, for
-//                     pure-ACGT sequences, a PACKED image (2 bits/base, 16 per dword, base k of a
-//                     dword in bits 2k..2k+1).  Each image is followed by SWMI_SEQ_PAD_WORDS zero
-//                     dwords so a 16-step block may over-read past the end.
+//   seqw   uint32[]   every sequence as a BYTE image: 1 canonical code per base, 4 per dword, image start
+//                     16-byte aligned.  Codes: A,C,G,T (any case) -> 0,8,16,24 -- the bit offset of the
+//                     base's entry in a row's 4 x int8 score profile, so the fill kernel's lookup is one
+//                     v_bfe_i32 -- every other (upper-cased) byte value -> a distinct code outside that set.
+//                     Each image is followed by SWMI_SEQ_PAD_WORDS zero dwords so a 16-step block may
+//                     over-read past the end.
 //   refs / reads      SeqDesc per sequence.
 //   pairs  PairDesc[] one per (ref, read) pair of the launch (any order; the host sorts by work).
 //   dir    uint32[]   direction field, 2 bits per DP cell.  For one pair and one strip of 64*R
 //                     read rows it is laid out [w][k][lane]: dword ((w*R + k)*64 + lane) holds the
 //                     16 anti-diagonal steps t = 16w .. 16w+15 of row i = strip*64R + lane*R + k + 1,
 //                     step t at bits 2*(15 - t%16) (+1), where lane `lane` is at column j = t - lane + 1.
+//                     Code: bit0 = alignment chosen, else bit1 = insertion chosen, else deletion.
 //                     Every store instruction therefore writes 256 contiguous bytes.
 //   cells  uint2[]    per pair, up to cell_cap (i, j) coordinates of the tied maximum cells.
 //   out    PairOut[]  per pair score / count / flags.
@@ -25,14 +28,13 @@
 #endif
 
 #define SWMI_SEQ_PAD_WORDS 24u
-#define SWMI_NO_PACKED     0xFFFFFFFFu
 #define SWMI_RMAX          4          // rows per lane in the widest kernel variant
 #define SWMI_CODE_PAD      0x1FFu     // never equals a base code (codes are 0..255)
 
-// direction codes stored in the field (2 bits): bit1 = alignment chosen, bit0 = insertion chosen
+// op codes of an alignment record (2 bits per traceback step)
 #define SWMI_DIR_D 0u
 #define SWMI_DIR_I 1u
-#define SWMI_DIR_A 2u   // 2 or 3
+#define SWMI_DIR_A 2u
 
 // PairOut.flags
 #define SWMI_F_DEGENERATE   0x1u   // max score 0: all m*n cells tie (no alignment records emitted)
@@ -41,8 +43,8 @@
 
 struct SeqDesc {
     uint32_t len;     // bases
-    uint32_t boff;    // dword offset of the byte image in seqw
-    uint32_t poff;    // dword offset of the packed image, SWMI_NO_PACKED if the sequence is not pure ACGT
+    uint32_t boff;    // dword offset of the byte image in seqw (multiple of 4)
+    uint32_t acgt;    // 1 if every base is A/C/G/T (codes 0,8,16,24)
     uint32_t pad;
 };
 
@@ -88,6 +90,10 @@ struct FillArgs {
     uint2          *cells;
     const uint64_t *cells_off;   // per out_id offset into cells[] (null: out_id * cell_cap)
     const uint32_t *cells_cap;   // per out_id capacity        (null: cell_cap)
+    ArenaHdr       *hdr;         // zeroed by the fill kernel for the traceback kernel that follows it
+    unsigned long long *dbg;     // optional diagnostics: per pair {slow-path entries, s_memtime ticks}
+    uint32_t        dbg_thr0;    // diagnostics only: initial threshold (timing runs without the rare path)
+    uint32_t        dbg_pad;
     uint32_t        n_pairs;
     uint32_t        cell_cap;
     int32_t         match, mismatch, gap;
@@ -112,6 +118,8 @@ struct TraceArgs {
     int32_t         match, mismatch, gap;
     uint32_t        strict;
     uint32_t        lds_words;   // staging words per block for the ops of one alignment
+    uint32_t        lds_read_words;   // LDS dwords reserved for the longest read's codes
+    unsigned long long *dbg;     // optional diagnostics: per pair {ticks, walk ticks, steps, tiles}
 };
 
 // rows per lane for a read of m bases

@@ -38,14 +38,23 @@
 __device__ __forceinline__ int wave_shr1(int old, int src) {
     return __builtin_amdgcn_update_dpp(old, src, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
 }
+// same, lane 0 receives 0 (bound_ctrl)
+__device__ __forceinline__ int wave_shr1_zero(int src) {
+    return __builtin_amdgcn_update_dpp(0, src, 0x138 /*wave_shr:1*/, 0xf, 0xf, true);
+}
 
+// wave-wide signed max through the DPP network (no LDS): 4 row steps, 2 row broadcasts, result read from lane 63
 __device__ __forceinline__ int wave_max_i32(int v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        int o = __shfl_xor(v, off, WAVE);
-        v = v > o ? v : o;
-    }
-    return v;
+#define SWMI_DPP_MAX(ctrl, rmask)                                                          \
+    { int o_ = __builtin_amdgcn_update_dpp(v, v, ctrl, rmask, 0xf, false); v = v > o_ ? v : o_; }
+    SWMI_DPP_MAX(0x111, 0xf)   // row_shr:1
+    SWMI_DPP_MAX(0x112, 0xf)   // row_shr:2
+    SWMI_DPP_MAX(0x114, 0xf)   // row_shr:4
+    SWMI_DPP_MAX(0x118, 0xf)   // row_shr:8   -> lane 15 of every row holds the row's max
+    SWMI_DPP_MAX(0x142, 0xa)   // row_bcast:15 into rows 1 and 3
+    SWMI_DPP_MAX(0x143, 0xc)   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's max
+#undef SWMI_DPP_MAX
+    return __builtin_amdgcn_readlane(v, 63);
 }
 
 __device__ __forceinline__ uint32_t lanemask_lt_count(uint64_t mask) {
@@ -53,35 +62,173 @@ __device__ __forceinline__ uint32_t lanemask_lt_count(uint64_t mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
-// acc = 2*acc + bit, the bit coming straight from a compare's lane mask (v_cmp + v_addc_co_u32).
-__device__ __forceinline__ uint32_t push_bit(uint32_t acc, bool bit) {
-    return acc + acc + (bit ? 1u : 0u);
-}
-
-// a value every lane holds identically -> scalar register (keeps the per-step base extraction on the SALU)
-__device__ __forceinline__ uint32_t uniform_u32(uint32_t v) {
-    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
-}
-
-__device__ __forceinline__ uint32_t seq_code_bytes(const uint32_t *__restrict__ w, uint32_t pos) {
+__device__ __forceinline__ uint32_t seq_code(const uint32_t *__restrict__ w, uint32_t pos) {
     return (w[pos >> 2] >> (8u * (pos & 3u))) & 0xFFu;
 }
-__device__ __forceinline__ uint32_t seq_code_packed(const uint32_t *__restrict__ w, uint32_t pos) {
-    return (w[pos >> 4] >> (2u * (pos & 15u))) & 3u;
+
+// ------------------------------------------------------------------------------------------------
+// the R cells of one lane in one step (previous column's H in hin, this column's H to hout)
+// ------------------------------------------------------------------------------------------------
+#include "swmi_cells_gen.inc"   // CellsAsm<R, ACGT, STRICT>: hand-scheduled instruction stream
+
+// Plain C++ statement of the same update (build with -DSWMI_NO_ASM to A/B against the asm stream).
+template <int R, bool ACGT, bool STRICT>
+struct CellsRef {
+    static __device__ __forceinline__ void step(const int (&hin)[R], int (&hout)[R], uint32_t (&acc)[R], const int (&q)[R],
+                                                int rb, int diag, int up, int gap, int vmat, int vmis) {
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const int left = hin[k];
+            int sc;
+            if (ACGT) sc = __builtin_amdgcn_sbfe(q[k], (unsigned)rb, 8u);
+            else      sc = (rb == q[k]) ? vmat : vmis;
+            const int a = diag + sc;                       // SmithWaterman.java:244 / AlignmentScore :309-318
+            const int t2 = (up > left ? up : left) + gap;   // :227, :235 (InsDelScore :277-280)
+            int hv = a > t2 ? a : t2;
+            hv = hv > 0 ? hv : 0;                           // `int max = 0` :223
+            const bool bi = STRICT ? (up > left) : (up >= left);
+            const bool ba = STRICT ? (a > t2) : (a >= t2);
+            acc[k] = (acc[k] << 2) | (bi ? 2u : 0u) | (ba ? 1u : 0u);
+            diag = left;
+            up = hv;
+            hout[k] = hv;
+        }
+    }
+};
+
+#ifdef SWMI_NO_ASM
+template <int R, bool ACGT, bool STRICT> using Cells = CellsRef<R, ACGT, STRICT>;
+#else
+template <int R, bool ACGT, bool STRICT> using Cells = CellsAsm<R, ACGT, STRICT>;
+#endif
+
+// ------------------------------------------------------------------------------------------------
+// rare path: at step t some lane reached the running maximum.  Out of line so the 16x unrolled hot
+// block stays small.  thr / cnt are wave-uniform; they travel packed in one 64-bit value.
+// ------------------------------------------------------------------------------------------------
+template <int R>
+__device__ __forceinline__ unsigned long long
+record_max_cells(int h0, int h1, int h2, int h3, uint32_t t, uint32_t lane_eff, uint32_t n, uint32_t row0, uint32_t m,
+                 int thr, uint32_t cnt, uint2 *__restrict__ cells, uint32_t ccap) {
+    const int hh[4] = {h0, h1, h2, h3};
+    const uint32_t c0 = t - lane_eff;                  // column index j-1 the lane worked on at step t
+    const bool active = c0 < n;
+    int cand = -1;
+#pragma unroll
+    for (int k = 0; k < R; ++k)
+        if (active && row0 + k < m) cand = cand > hh[k] ? cand : hh[k];
+    const int wmax = wave_max_i32(cand);
+    if (wmax >= thr) {
+        if (wmax > thr) { thr = wmax; cnt = 0; }        // SmithWaterman.java:176-181
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const bool hit = active && (row0 + k < m) && (hh[k] == thr);   // :182-185
+            const uint64_t hm = __ballot(hit);
+            if (hm) {
+                const uint32_t pos = cnt + lanemask_lt_count(hm);
+                if (hit && pos < ccap) cells[pos] = make_uint2(row0 + k + 1, c0 + 1u);
+                cnt += (uint32_t)__popcll(hm);
+            }
+        }
+    }
+    return ((unsigned long long)(uint32_t)thr << 32) | cnt;
 }
 
 // ------------------------------------------------------------------------------------------------
-// fill: one pair, one wavefront.  R rows per lane; ACGT = both sequences pure ACGT (profile lookup
-// by v_bfe_i32 instead of compare+select); STRICT = DistributedSW tie order; MULTI = more than one
-// strip of 64*R rows (seam row through memory).
+// fill: one pair, one wavefront.  R rows per lane; ACGT = both sequences pure ACGT and scores fit a
+// signed byte (profile lookup by v_bfe_i32 instead of compare+select); STRICT = DistributedSW tie order;
+// MULTI = more than one strip of 64*R rows (seam row through memory).
 // ------------------------------------------------------------------------------------------------
+template <int R>
+struct FillState {
+    int h[R];            // H of the lane's rows after the latest even-numbered... see fill_block16: ping
+    int g[R];            // pong
+    uint32_t acc[R];
+    int q[R];
+    int nprev, rb;
+    int thr;             // wave-uniform running maximum
+    uint32_t cnt;        // wave-uniform number of cells equal to thr
+    uint64_t ev_prev;    // lanes whose previous step reached thr (handled one step late, see below)
+    uint32_t events;     // slow-path entries (diagnostics only)
+};
+
+template <int R>
+__device__ __forceinline__ void handle_pending(FillState<R> &S, const int (&hv)[R], uint32_t t, uint32_t lane_eff,
+                                               uint32_t n, uint32_t row0, uint32_t m, uint2 *__restrict__ cells, uint32_t ccap) {
+    const unsigned long long tc = record_max_cells<R>(
+        hv[0], R > 1 ? hv[R > 1 ? 1 : 0] : 0, R > 2 ? hv[R > 2 ? 2 : 0] : 0, R > 3 ? hv[R > 3 ? 3 : 0] : 0,
+        t, lane_eff, n, row0, m, S.thr, S.cnt, cells, ccap);
+    S.events++;
+    S.thr = __builtin_amdgcn_readfirstlane((int)(tc >> 32));
+    S.cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)tc);
+}
+
+// 16 anti-diagonal steps t = t0 .. t0+15.  PRED: lanes may be outside their column range (ramp-up /
+// ramp-down blocks); otherwise every lane below `lact` is inside it for all 16 steps.
+//
+// The H registers ping-pong between S.h (read by even steps) and S.g (read by odd steps), so after step t
+// the values of step t-1 are still there.  That lets the tied-maximum test of step t-1 -- a compare into
+// an SGPR pair -- be branched on one step later, when its result has long arrived, instead of stalling the
+// wave on a VALU->scalar-branch dependency every step (measured: 57 of 197 cycles per step).
+template <int R, bool ACGT, bool STRICT, bool MULTI, bool PRED>
+__device__ __forceinline__ void fill_block16(FillState<R> &S, const uint4 w, const uint32_t t0,
+                                             const uint32_t lane, const uint32_t lane_eff,
+                                             const uint32_t n, const uint32_t m, const uint32_t row0,
+                                             const int gap, const int vmat, const int vmis,
+                                             const int seamv, const bool reads_seam, const bool feeds_seam,
+                                             int32_t *__restrict__ seam_out,
+                                             uint2 *__restrict__ cells, const uint32_t ccap) {
+#pragma unroll
+    for (uint32_t s = 0; s < 16; ++s) {
+        const int (&hin)[R] = (s & 1u) ? S.g : S.h;
+        int (&hout)[R] = (s & 1u) ? S.h : S.g;
+        const uint32_t wsel = s < 4 ? w.x : s < 8 ? w.y : s < 12 ? w.z : w.w;
+        const int feed = (int)((wsel >> (8u * (s & 3u))) & 0xFFu);        // base code of column t0+s+1 (lane 0)
+        S.rb = wave_shr1(feed, S.rb);
+        int nin;
+        if (MULTI) {
+            int topn = 0;
+            if (reads_seam) topn = __builtin_amdgcn_readlane(seamv, s);
+            nin = wave_shr1(topn, hin[R - 1]);
+        } else {
+            nin = wave_shr1_zero(hin[R - 1]);
+        }
+        int mrow;
+        if (PRED) {
+            const uint32_t c0 = t0 + s - lane_eff;                         // column index j-1 of this lane
+            mrow = -1;
+            if (c0 < n) {
+                Cells<R, ACGT, STRICT>::step(hin, hout, S.acc, S.q, S.rb, S.nprev, nin, gap, vmat, vmis);
+                mrow = hout[0];
+#pragma unroll
+                for (int k = 1; k < R; ++k) mrow = mrow > hout[k] ? mrow : hout[k];
+                if (MULTI && feeds_seam && lane == WAVE - 1) seam_out[c0 + 1] = hout[R - 1];
+            } else {
+#pragma unroll
+                for (int k = 0; k < R; ++k) hout[k] = hin[k];             // a lane off its range keeps its state
+            }
+        } else {
+            Cells<R, ACGT, STRICT>::step(hin, hout, S.acc, S.q, S.rb, S.nprev, nin, gap, vmat, vmis);
+            mrow = hout[0];
+#pragma unroll
+            for (int k = 1; k < R; ++k) mrow = mrow > hout[k] ? mrow : hout[k];
+            if (MULTI && feeds_seam && lane == WAVE - 1) seam_out[t0 + s - lane + 1] = hout[R - 1];
+        }
+        S.nprev = nin;
+        const uint64_t ev = __ballot(mrow >= S.thr);
+        if (__builtin_expect(S.ev_prev != 0, 0))                           // step t0+s-1, values still in hin
+            handle_pending<R>(S, hin, t0 + s - 1u, lane_eff, n, row0, m, cells, ccap);
+        S.ev_prev = ev;
+    }
+}
+
 template <int R, bool ACGT, bool STRICT, bool MULTI>
 __device__ __forceinline__ void fill_pair(const FillArgs &A, const PairDesc pd, const uint32_t lane) {
     const SeqDesc rd = A.refs[pd.ref_id];
     const SeqDesc qd = A.reads[pd.read_id];
     const uint32_t n = rd.len, m = qd.len;
-    const uint32_t *__restrict__ refw = A.seqw + (ACGT ? rd.poff : rd.boff);
-    const uint32_t *__restrict__ readw = A.seqw + (ACGT ? qd.poff : qd.boff);
+    const uint32_t *__restrict__ refw = A.seqw + rd.boff;
+    const uint32_t *__restrict__ readw = A.seqw + qd.boff;
     const int match = A.match, mismatch = A.mismatch, gap = A.gap;
 
     const uint32_t rps = WAVE * R;                       // rows per strip
@@ -93,40 +240,40 @@ __device__ __forceinline__ void fill_pair(const FillArgs &A, const PairDesc pd, 
     const uint32_t ccap = A.cells_cap ? A.cells_cap[pd.out_id] : A.cell_cap;
     uint2 *__restrict__ cells = A.cells + cbase;
 
-    int thr = 1;             // wave-uniform running maximum (a max of 0 never enters the list: degenerate case)
-    uint32_t cnt = 0;        // wave-uniform number of cells equal to thr
+    FillState<R> S;
+    S.thr = A.dbg ? (int)A.dbg_thr0 : 1;   // a max of 0 never enters the list: that is the degenerate case
+    S.cnt = 0;
+    S.ev_prev = 0;
+    S.events = 0;
+    const unsigned long long t_start = A.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
 
     for (uint32_t s = 0; s < n_strips; ++s) {
         const uint32_t row0 = s * rps + lane * R;        // 0-based first row of this lane
         const uint32_t rows_left = m - s * rps;
         const uint32_t lact = rows_left >= rps ? WAVE : (rows_left + R - 1) / R;   // lanes holding rows
         const uint32_t T = n + lact - 1;                 // steps of this strip
+        const uint32_t lane_eff = lane < lact ? lane : 0x40000000u;   // lanes without rows are never in range
 
         // read-side operands of this lane's rows
-        int q[R];                                        // ACGT: 4 signed score bytes; else the base code
 #pragma unroll
         for (int k = 0; k < R; ++k) {
             const uint32_t row = row0 + k;
-            if (ACGT) {
+            if (ACGT) {                                   // 4 signed score bytes indexed by the reference code
                 uint32_t p = (uint32_t)(mismatch & 0xFF) * 0x01010101u;
                 if (row < m) {
-                    const uint32_t c = seq_code_packed(readw, row);
-                    p = (p & ~(0xFFu << (8u * c))) | ((uint32_t)(match & 0xFF) << (8u * c));
+                    const uint32_t c = seq_code(readw, row);      // 0, 8, 16 or 24
+                    p = (p & ~(0xFFu << c)) | ((uint32_t)(match & 0xFF) << c);
                 }
-                q[k] = (int)p;
+                S.q[k] = (int)p;
             } else {
-                q[k] = row < m ? (int)seq_code_bytes(readw, row) : (int)SWMI_CODE_PAD;
+                S.q[k] = row < m ? (int)seq_code(readw, row) : (int)SWMI_CODE_PAD;
             }
+            S.h[k] = 0;
+            S.g[k] = 0;
+            S.acc[k] = 0;
         }
-
-        int h[R];
-        uint32_t acc[R];
-#pragma unroll
-        for (int k = 0; k < R; ++k) { h[k] = 0; acc[k] = 0; }
-        int nprev = 0;                                   // N received one step earlier = NW of this step
-        int hb = 0;                                      // bottom-row H of the previous step (what lane l+1 reads)
-        int rb = 0;                                      // reference base operand of this lane's current column
-        int c0 = lane < lact ? -(int)lane - 1 : -(1 << 30);   // after the step's increment: c0 = j - 1
+        S.nprev = 0;                                     // N received one step earlier = NW of this step
+        S.rb = 0;                                        // reference base operand of this lane's current column
 
         uint32_t *__restrict__ dirp = A.dir + pd.dir_off + s * strip_words + lane;
         const int32_t *seam_in = nullptr;
@@ -140,110 +287,53 @@ __device__ __forceinline__ void fill_pair(const FillArgs &A, const PairDesc pd, 
         const bool reads_seam = MULTI && (s > 0);
 
         const uint32_t nblk = (T + 15u) / 16u;
+        const uint4 *__restrict__ refq = reinterpret_cast<const uint4 *>(refw);   // images are 16-byte aligned
+        uint4 wnext = refq[0];
         for (uint32_t tb = 0; tb < nblk; ++tb) {
-            // reference codes of columns 16tb+1 .. 16tb+16 for lane 0 (wave-uniform, scalar registers)
-            uint32_t rw0, rw1 = 0, rw2 = 0, rw3 = 0;
-            if (ACGT) {
-                rw0 = uniform_u32(refw[tb]);
-            } else {
-                rw0 = uniform_u32(refw[4 * tb]);     rw1 = uniform_u32(refw[4 * tb + 1]);
-                rw2 = uniform_u32(refw[4 * tb + 2]); rw3 = uniform_u32(refw[4 * tb + 3]);
-            }
+            const uint4 w = wnext;                       // base codes of columns 16tb+1 .. 16tb+16
+            wnext = refq[tb + 1];                        // prefetch (images are padded)
+            const uint32_t t0 = 16u * tb;
             int seamv = 0;
             if (reads_seam) {
                 // seam_in[16tb + 1 + lane] for lanes 0..15: N of lane 0 for the 16 steps of this block
-                const uint32_t col = 16u * tb + 1u + (lane & 15u);
+                const uint32_t col = t0 + 1u + (lane & 15u);
                 seamv = col <= n ? __hip_atomic_load(seam_in + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
             }
-
-#pragma unroll 4
-            for (uint32_t sidx = 0; sidx < 16; ++sidx) {
-                // ---- cross-lane part, all 64 lanes ------------------------------------------------
-                uint32_t code;
-                if (ACGT) {
-                    code = ((rw0 >> (2u * sidx)) & 3u) * 8u;                    // bit offset into the profile
-                } else {
-                    const uint32_t wsel = (sidx >> 2) == 0 ? rw0 : (sidx >> 2) == 1 ? rw1 : (sidx >> 2) == 2 ? rw2 : rw3;
-                    code = (wsel >> (8u * (sidx & 3u))) & 0xFFu;
-                }
-                rb = wave_shr1((int)code, rb);
-                int topn = 0;
-                if (reads_seam) topn = __builtin_amdgcn_readlane(seamv, sidx);
-                const int nin = wave_shr1(topn, hb);
-                c0 += 1;
-                const bool active = (uint32_t)c0 < n;
-                int mrow = -1;                 // stays -1 in lanes that are off their column range
-                if (active) {
-                    int diag = nprev, up = nin;
-#pragma unroll
-                    for (int k = 0; k < R; ++k) {
-                        const int left = h[k];
-                        int sc;
-                        if (ACGT) sc = __builtin_amdgcn_sbfe(q[k], (unsigned)rb, 8u);
-                        else      sc = (rb == q[k]) ? match : mismatch;
-                        const int a = diag + sc;
-                        const int t2 = (up > left ? up : left) + gap;
-                        int hv = a > t2 ? a : t2;
-                        hv = hv > 0 ? hv : 0;
-                        const bool ba = STRICT ? (a > t2) : (a >= t2);
-                        const bool bi = STRICT ? (up > left) : (up >= left);
-                        acc[k] = push_bit(push_bit(acc[k], ba), bi);
-                        diag = left;
-                        up = hv;
-                        h[k] = hv;
-                    }
-                    hb = h[R - 1];
-                    mrow = h[0];
-#pragma unroll
-                    for (int k = 1; k < R; ++k) mrow = mrow > h[k] ? mrow : h[k];
-                    if (feeds_seam && lane == WAVE - 1) seam_out[c0 + 1] = hb;
-                }
-                nprev = nin;
-
-                // ---- rare: some lane reached the running maximum ---------------------------------
-                // all 64 lanes vote, so thr/cnt below stay wave-uniform
-                if (__builtin_expect(__ballot(mrow >= thr) != 0, 0)) {
-                    int cand = -1;
-#pragma unroll
-                    for (int k = 0; k < R; ++k)
-                        if (active && row0 + k < m) cand = cand > h[k] ? cand : h[k];
-                    const int wmax = wave_max_i32(cand);
-                    if (wmax >= thr) {
-                        if (wmax > thr) { thr = wmax; cnt = 0; }
-#pragma unroll
-                        for (int k = 0; k < R; ++k) {
-                            const bool hit = active && (row0 + k < m) && (h[k] == thr);
-                            const uint64_t hm = __ballot(hit);
-                            if (hm) {
-                                const uint32_t pos = cnt + lanemask_lt_count(hm);
-                                if (hit && pos < ccap) cells[pos] = make_uint2(row0 + k + 1, (uint32_t)c0 + 1u);
-                                cnt += (uint32_t)__popcll(hm);
-                            }
-                        }
-                    }
-                }
-            }
+            const bool steady = (t0 + 1u >= lact) && (t0 + 15u < n);
+            if (steady)
+                fill_block16<R, ACGT, STRICT, MULTI, false>(S, w, t0, lane, lane_eff, n, m, row0, gap, match, mismatch,
+                                                            seamv, reads_seam, feeds_seam, seam_out, cells, ccap);
+            else
+                fill_block16<R, ACGT, STRICT, MULTI, true>(S, w, t0, lane, lane_eff, n, m, row0, gap, match, mismatch,
+                                                           seamv, reads_seam, feeds_seam, seam_out, cells, ccap);
 
             // ---- end of a 16-step block: one coalesced 256 B store per row slot -------------------
             // lanes that finished their last column inside this block still owe the missing shifts
-            const int t_end = (int)(16u * tb + 15u);
-            const int t_last = (int)(lane + n) - 1;
-            const int miss = t_end - t_last;
+            const int miss = (int)(t0 + 15u) - ((int)(lane + n) - 1);
 #pragma unroll
             for (int k = 0; k < R; ++k) {
-                uint32_t v = acc[k];
+                uint32_t v = S.acc[k];
                 if (miss > 0 && miss < 16) v <<= 2 * miss;
                 dirp[((uint64_t)tb * R + k) * WAVE] = v;
             }
+        }
+        // the tied-maximum test of the strip's last step is still pending (16 steps per block: its H is in S.h)
+        if (S.ev_prev != 0) {
+            handle_pending<R>(S, S.h, 16u * nblk - 1u, lane_eff, n, row0, m, cells, ccap);
+            S.ev_prev = 0;
         }
         if (MULTI) __threadfence();    // seam row of this strip visible before the next strip reads it
     }
 
     if (lane == 0) {
         PairOut o;
-        if (cnt == 0) { o.score = 0; o.flags = SWMI_F_DEGENERATE; o.n_cells = (uint64_t)m * n; }
-        else          { o.score = thr; o.flags = cnt > ccap ? SWMI_F_CELL_OVF : 0u; o.n_cells = cnt; }
+        if (S.cnt == 0) { o.score = 0; o.flags = SWMI_F_DEGENERATE; o.n_cells = (uint64_t)m * n; }
+        else            { o.score = S.thr; o.flags = S.cnt > ccap ? SWMI_F_CELL_OVF : 0u; o.n_cells = S.cnt; }
         A.out[pd.out_id] = o;
+        if (A.dbg) {
+            A.dbg[2 * pd.out_id] = S.events;
+            A.dbg[2 * pd.out_id + 1] = __builtin_amdgcn_s_memtime() - t_start;
+        }
     }
 }
 
@@ -257,16 +347,21 @@ __device__ __forceinline__ void fill_dispatch(const FillArgs &A, const PairDesc 
     else             fill_pair<SWMI_RMAX, ACGT, STRICT, true>(A, pd, lane);
 }
 
-extern "C" __global__ void __launch_bounds__(WAVE)
+// 4 wavefronts per workgroup, one pair each: the 4 waves of a workgroup land on the 4 SIMDs of a CU, so a
+// grid of n_pairs/4 workgroups spreads evenly over the SIMDs (single-wave workgroups were observed to pile
+// up on some SIMDs, and this instruction mix saturates a SIMD with little more than one wave).
+#define FILL_WAVES 4
+extern "C" __global__ void __launch_bounds__(WAVE * FILL_WAVES)
 sw_fill_kernel(const FillArgs A) {
-    const uint32_t pair = blockIdx.x;
+    const uint32_t pair = blockIdx.x * FILL_WAVES + (threadIdx.x >> 6);
     if (pair >= A.n_pairs) return;
-    const uint32_t lane = threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    if (pair == 0 && lane == 0 && A.hdr) { A.hdr->used_words = 0; A.hdr->n_records = 0; }   // arena reset for the traceback kernel
     const PairDesc pd = A.pairs[pair];
     const SeqDesc rd = A.refs[pd.ref_id];
     const SeqDesc qd = A.reads[pd.read_id];
     // profile lookup needs both sequences pure ACGT and scores that fit a signed byte
-    const bool acgt = rd.poff != SWMI_NO_PACKED && qd.poff != SWMI_NO_PACKED &&
+    const bool acgt = rd.acgt && qd.acgt &&
                       A.match >= -128 && A.match <= 127 && A.mismatch >= -128 && A.mismatch <= 127;
     if (acgt) {
         if (A.strict) fill_dispatch<true, true>(A, pd, lane, qd.len);
@@ -278,98 +373,150 @@ sw_fill_kernel(const FillArgs A) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// traceback: one wavefront per pair
+// traceback: SWMI_TB_SLOTS wavefronts per pair (slot x walks the tied cells x, x+SLOTS, ...).
+//
+// The walk is a chain of dependent 2-bit lookups; straight from HBM that is ~1 us per step, and even from
+// LDS a one-cell-at-a-time scalar walk costs ~100 instruction issues per step.  So:
+//  * the wave copies a TILE of the direction field -- SWMI_TB_BLOCKS 16-step blocks x all 64*R row slots
+//    of the strip, i.e. every cell whose anti-diagonal step lies in a 256-step window -- into LDS with
+//    coalesced 256 B loads (all in flight at once), plus the matching window of reference codes and the
+//    whole read;
+//  * it then advances by RUNS: lane x looks at the cell x steps up the current diagonal, a ballot gives the
+//    length of the run of "alignment" moves, a second ballot over per-lane prefix scores finds where the
+//    tracked score H(pred) = H - s(ref,read) would reach 0 (`while (score > 0)`, SmithWaterman.java:380), and
+//    the whole run is emitted at once.  Gap moves (insertion / deletion) are taken one at a time.
 // ------------------------------------------------------------------------------------------------
-extern "C" __global__ void __launch_bounds__(WAVE)
-sw_traceback_kernel(const TraceArgs A) {
-    extern __shared__ uint32_t ops_lds[];
-    const uint32_t pair = blockIdx.x;
-    if (pair >= A.n_pairs) return;
-    const uint32_t lane = threadIdx.x;
-    const PairDesc pd = A.pairs[pair];
-    const PairOut po = A.out[pd.out_id];
-    if (po.flags & (SWMI_F_DEGENERATE | SWMI_F_CELL_OVF)) return;
+#define SWMI_TB_BLOCKS 16u
+#define SWMI_TB_REFWIN_WORDS 96u      // (16*16 + 63) / 4 + slack
+#define SWMI_TB_SLOTS 4u
 
+template <uint32_t R>
+__device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDesc pd, const PairOut po,
+                                               const uint32_t lane, const uint32_t slot, uint32_t *__restrict__ lds) {
     const SeqDesc rd = A.refs[pd.ref_id];
     const SeqDesc qd = A.reads[pd.read_id];
     const uint32_t n = rd.len, m = qd.len;
     const uint32_t *__restrict__ refw = A.seqw + rd.boff;
     const uint32_t *__restrict__ readw = A.seqw + qd.boff;
-    const uint32_t R = swmi_rows_per_lane(m);
     const uint32_t rps = WAVE * R;
     const uint32_t wblocks = (n + 63u + 15u) / 16u;
     const uint64_t strip_words = (uint64_t)wblocks * R * WAVE;
     const uint32_t *__restrict__ dirp = A.dir + pd.dir_off;
+    const uint32_t umat = (uint32_t)A.match, umis = (uint32_t)A.mismatch, ugap = (uint32_t)A.gap;
+
+    uint32_t *lds_ops = lds;                                   // [A.lds_words]      one op per BYTE, staged per alignment
+    uint32_t *lds_read = lds_ops + A.lds_words;                // [A.lds_read_words] the read's codes
+    uint32_t *lds_ref = lds_read + A.lds_read_words;           // [SWMI_TB_REFWIN_WORDS]
+    uint32_t *lds_tile = lds_ref + SWMI_TB_REFWIN_WORDS;       // [SWMI_TB_BLOCKS * R * 64]
+    uint8_t *ops_b = reinterpret_cast<uint8_t *>(lds_ops);
+    const uint8_t *read_b = reinterpret_cast<const uint8_t *>(lds_read);
+    const uint8_t *ref_b = reinterpret_cast<const uint8_t *>(lds_ref);
+
+    const unsigned long long tk0 = A.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
+    unsigned long long tk_walk = 0, n_steps = 0, n_iters = 0;
+    for (uint32_t w = lane; w < (m + 3u) / 4u; w += WAVE) lds_read[w] = readw[w];
 
     const uint64_t cbase = A.cells_off ? A.cells_off[pd.out_id] : (uint64_t)pd.out_id * A.cell_cap;
     const uint32_t ncell = (uint32_t)po.n_cells;
     const uint2 *__restrict__ cells = A.cells + cbase;
 
-    // Process the tied cells in the order the reference lists them: row-major (SmithWaterman.java:157-185)
-    // or per anti-diagonal with ascending j (DistributedSW.java:209-239).  Lists are short (<= cell_cap) in
-    // the fast path; the re-run path may hand over long ones, so rank in chunks of 64.
+    // The tied cells are processed in list order; `rank` is the position the reference would list the cell
+    // at: row-major (SmithWaterman.java:157-185) or per anti-diagonal, ascending j (DistributedSW.java:209-239).
     for (uint32_t base = 0; base < ncell; base += WAVE) {
         const uint32_t idx = base + lane;
         uint2 mine = make_uint2(0, 0);
         if (idx < ncell) mine = cells[idx];
         const uint64_t mykey = A.strict ? (((uint64_t)(mine.x + mine.y) << 32) | mine.y)
                                         : (((uint64_t)mine.x << 32) | mine.y);
-        // rank of my cell among all cells of the pair
         uint32_t rank = 0;
-        for (uint32_t o = 0; o < ncell; ++o) {
-            const uint2 c = cells[o];
-            const uint64_t k = A.strict ? (((uint64_t)(c.x + c.y) << 32) | c.y) : (((uint64_t)c.x << 32) | c.y);
-            rank += (k < mykey) ? 1u : 0u;
+        if (ncell > 1) {
+            for (uint32_t o = 0; o < ncell; ++o) {
+                const uint2 c = cells[o];
+                const uint64_t kk = A.strict ? (((uint64_t)(c.x + c.y) << 32) | c.y) : (((uint64_t)c.x << 32) | c.y);
+                rank += (kk < mykey) ? 1u : 0u;
+            }
         }
         const uint32_t nhere = ncell - base < WAVE ? ncell - base : WAVE;
 
-        for (uint32_t a = 0; a < nhere; ++a) {
+        for (uint32_t a = slot; a < nhere; a += SWMI_TB_SLOTS) {
             const uint32_t ci = __builtin_amdgcn_readlane((int)mine.x, a);
             const uint32_t cj = __builtin_amdgcn_readlane((int)mine.y, a);
             const uint32_t crank = __builtin_amdgcn_readlane((int)rank, a);
 
-            // ---- walk (lane 0), SmithWaterman.java:380-409 ----
+            // ---- walk, SmithWaterman.java:380-409; (i, j, score, n_ops, begin) are wave-uniform ----
+            uint32_t i = ci, j = cj;
+            uint32_t score = (uint32_t)po.score;
             uint32_t n_ops = 0;
             int begin = 0;
-            if (lane == 0) {
-                uint32_t i = ci, j = cj;
-                int score = po.score;
-                uint32_t word = 0;
-                while (score > 0) {
-                    begin = (int)j;
-                    const uint32_t r0 = i - 1;
-                    const uint32_t s = r0 / rps, rl = r0 % rps;
-                    const uint32_t l = rl / R, k = rl % R;
-                    const uint32_t t = (j - 1) + l;
-                    const uint32_t dw = dirp[s * strip_words + ((uint64_t)(t >> 4) * R + k) * WAVE + l];
-                    const uint32_t d = (dw >> (2u * (15u - (t & 15u)))) & 3u;
-                    uint32_t op;
-                    if (d & 2u) {          // alignment: H(i-1,j-1) = H - s(ref[j-1], read[i-1])
-                        const uint32_t rc = seq_code_bytes(refw, j - 1), qc = seq_code_bytes(readw, i - 1);
-                        score = (int)((uint32_t)score - (uint32_t)(rc == qc ? A.match : A.mismatch));
-                        --i; --j; op = SWMI_DIR_A;
-                    } else if (d & 1u) {   // insertion: H(i-1,j) = H - gap
-                        score = (int)((uint32_t)score - (uint32_t)A.gap);
-                        --i; op = SWMI_DIR_I;
-                    } else {               // deletion: H(i,j-1) = H - gap
-                        score = (int)((uint32_t)score - (uint32_t)A.gap);
-                        --j; op = SWMI_DIR_D;
+            while ((int)score > 0) {
+                // ---- stage the tile that ends at the current cell's step ----
+                const uint32_t s = (i - 1u) / rps;
+                int rho = (int)((i - 1u) - s * rps);                               // row slot within the strip
+                const uint32_t t_cur = j - 1u + (uint32_t)rho / R;
+                const uint32_t whi = t_cur >> 4;
+                const uint32_t wlo = whi >= SWMI_TB_BLOCKS - 1u ? whi - (SWMI_TB_BLOCKS - 1u) : 0u;
+                const uint32_t nb = whi - wlo + 1u;
+                const uint32_t *__restrict__ src = dirp + s * strip_words + (uint64_t)wlo * R * WAVE + lane;
+                __syncthreads();
+                for (uint32_t x = 0; x < nb * R; ++x) lds_tile[x * WAVE + lane] = src[(uint64_t)x * WAVE];
+                const int clo = (int)(16u * wlo) - 63;
+                const uint32_t cw0 = clo > 0 ? (uint32_t)clo >> 2 : 0u;           // first dword of the reference window
+                const uint32_t cw1 = (16u * whi + 15u) >> 2;
+                for (uint32_t x = cw0 + lane; x <= cw1 && x < (n + 3u) / 4u; x += WAVE) lds_ref[x - cw0] = refw[x];
+                __syncthreads();
+                const int tmin = (int)(16u * wlo);
+
+                const unsigned long long tw0 = A.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
+
+                for (;;) {
+                    ++n_iters;
+                    // lane x: the cell x steps up the diagonal, (i - x, j - x)
+                    const int rho_x = rho - (int)lane;
+                    const uint32_t rx = rho_x > 0 ? (uint32_t)rho_x : 0u;
+                    const uint32_t lx = rx / R, kx = rx - lx * R;
+                    const int tx = (int)(j - lane) - 1 + (int)lx;
+                    const bool valid = rho_x >= 0 && j > lane && tx >= tmin;
+                    uint32_t d = 0;
+                    if (valid) {
+                        const uint32_t dw = lds_tile[(((uint32_t)tx >> 4) - wlo) * (R * WAVE) + kx * WAVE + lx];
+                        d = (dw >> (2u * (15u - ((uint32_t)tx & 15u)))) & 3u;
                     }
-                    word |= op << (2u * (n_ops & 15u));
-                    if ((n_ops & 15u) == 15u) {
-                        if ((n_ops >> 4) < A.lds_words) ops_lds[n_ops >> 4] = word;
-                        word = 0;
+                    if (!(__ballot(valid) & 1ull)) break;                          // current cell left the tile / the strip: restage
+                    const uint64_t amask = __ballot(valid && (d & 1u));
+                    uint32_t run = ~amask == 0ull ? 64u : (uint32_t)__builtin_ctzll(~amask);
+                    if (run == 0) {
+                        // the current cell is an insertion or a deletion: H(pred) = H - gap   (:395-406)
+                        const uint32_t d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
+                        begin = (int)j;                                             // :383
+                        score -= ugap;
+                        uint32_t op;
+                        if (d0 & 2u) { --i; --rho; op = SWMI_DIR_I; } else { --j; op = SWMI_DIR_D; }
+                        if (lane == 0 && n_ops < 4u * A.lds_words) ops_b[n_ops] = (uint8_t)op;
+                        n_ops += 1u;
+                    } else {
+                        // a run of alignment moves: H(i-1,j-1) = H - s(ref[j-1], read[i-1])   (:388-394)
+                        bool mt = false;
+                        if (lane < run) mt = ref_b[(j - 1u - lane) - 4u * cw0] == read_b[i - 1u - lane];
+                        const uint64_t mm = __ballot(mt);
+                        const uint32_t cm = lanemask_lt_count(mm) + (mt ? 1u : 0u);          // matches among lanes 0..x
+                        const uint32_t after = score - (cm * umat + (lane + 1u - cm) * umis);   // H after x+1 moves
+                        const uint64_t z = __ballot(lane < run && (int)after <= 0);
+                        if (z) run = (uint32_t)__builtin_ctzll(z) + 1u;              // `while (score > 0)` stops there
+                        score = (uint32_t)__builtin_amdgcn_readlane((int)after, run - 1u);
+                        begin = (int)(j - (run - 1u));
+                        if (lane < run && n_ops + lane < 4u * A.lds_words) ops_b[n_ops + lane] = (uint8_t)SWMI_DIR_A;
+                        n_ops += run; i -= run; j -= run; rho -= (int)run;
                     }
-                    ++n_ops;
-                    if (i == 0 || j == 0) break;       // H is 0 on the border: the loop ends there too
+                    if ((int)score <= 0) break;
+                    if (i == 0 || j == 0) { score = 0; break; }                      // H is 0 on the border
+                    if (rho < 0) break;                                             // continues in the strip above
                 }
-                if ((n_ops & 15u) != 0u && (n_ops >> 4) < A.lds_words) ops_lds[n_ops >> 4] = word;
+                if (A.dbg) tk_walk += __builtin_amdgcn_s_memtime() - tw0;
             }
-            n_ops = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_ops);
-            begin = __builtin_amdgcn_readfirstlane(begin);
+            n_steps += n_ops;
             __syncthreads();
 
-            // ---- append the record ----
+            // ---- append the record: header + ops packed 2 bits each (16 per dword) ----
             const uint32_t opw = (n_ops + 15u) / 16u;
             const uint32_t words = SWMI_ALNREC_WORDS + opw;
             unsigned long long off = 0;
@@ -379,19 +526,54 @@ sw_traceback_kernel(const TraceArgs A) {
             }
             off = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(off >> 32)) << 32) |
                   (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)off);
-            if (off + words <= A.arena_cap_words && opw <= A.lds_words) {
+            if (off + words <= A.arena_cap_words && n_ops <= 4u * A.lds_words) {
                 uint32_t *dst = A.arena + off;
                 if (lane == 0) {
                     dst[0] = pd.out_id; dst[1] = crank; dst[2] = (uint32_t)begin;
                     dst[3] = ci; dst[4] = cj; dst[5] = n_ops;
                 }
-                for (uint32_t w = lane; w < opw; w += WAVE) dst[SWMI_ALNREC_WORDS + w] = ops_lds[w];
+                for (uint32_t w = lane; w < opw; w += WAVE) {
+                    uint32_t packed = 0;
+#pragma unroll
+                    for (uint32_t c = 0; c < 4; ++c) {
+                        const uint32_t first = 16u * w + 4u * c;
+                        uint32_t x = first < n_ops ? lds_ops[4u * w + c] : 0u;
+                        if (first + 4u > n_ops && first < n_ops) x &= (1u << (8u * (n_ops - first))) - 1u;
+                        const uint32_t b8 = (x & 3u) | ((x >> 6) & 0xCu) | ((x >> 12) & 0x30u) | ((x >> 18) & 0xC0u);
+                        packed |= b8 << (8u * c);
+                    }
+                    dst[SWMI_ALNREC_WORDS + w] = packed;
+                }
             } else if (lane == 0) {
                 atomicOr(&A.out[pd.out_id].flags, SWMI_F_ARENA_OVF);
             }
             __syncthreads();
         }
     }
+    if (A.dbg && lane == 0 && slot == 0) {
+        A.dbg[4 * pd.out_id] = __builtin_amdgcn_s_memtime() - tk0;
+        A.dbg[4 * pd.out_id + 1] = tk_walk;
+        A.dbg[4 * pd.out_id + 2] = n_steps;
+        A.dbg[4 * pd.out_id + 3] = n_iters;
+    }
+}
+
+extern "C" __global__ void __launch_bounds__(WAVE)
+sw_traceback_kernel(const TraceArgs A) {
+    extern __shared__ uint32_t tb_lds[];
+    const uint32_t pair = blockIdx.x;
+    if (pair >= A.n_pairs) return;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t slot = blockIdx.y;
+    const PairDesc pd = A.pairs[pair];
+    const PairOut po = A.out[pd.out_id];
+    if (po.flags & (SWMI_F_DEGENERATE | SWMI_F_CELL_OVF)) return;
+    if (po.n_cells <= slot) return;
+    const uint32_t R = swmi_rows_per_lane(A.reads[pd.read_id].len);
+    if (R == 1)      traceback_pair<1>(A, pd, po, lane, slot, tb_lds);
+    else if (R == 2) traceback_pair<2>(A, pd, po, lane, slot, tb_lds);
+    else if (R == 3) traceback_pair<3>(A, pd, po, lane, slot, tb_lds);
+    else             traceback_pair<4>(A, pd, po, lane, slot, tb_lds);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -399,12 +581,14 @@ sw_traceback_kernel(const TraceArgs A) {
 // ------------------------------------------------------------------------------------------------
 extern "C" hipError_t swmi_launch_fill(const FillArgs *a, hipStream_t st) {
     if (a->n_pairs == 0) return hipSuccess;
-    hipLaunchKernelGGL(sw_fill_kernel, dim3(a->n_pairs), dim3(WAVE), 0, st, *a);
+    hipLaunchKernelGGL(sw_fill_kernel, dim3((a->n_pairs + FILL_WAVES - 1) / FILL_WAVES), dim3(WAVE * FILL_WAVES), 0, st, *a);
     return hipGetLastError();
 }
 
 extern "C" hipError_t swmi_launch_traceback(const TraceArgs *a, hipStream_t st) {
     if (a->n_pairs == 0) return hipSuccess;
-    hipLaunchKernelGGL(sw_traceback_kernel, dim3(a->n_pairs), dim3(WAVE), a->lds_words * sizeof(uint32_t), st, *a);
+    const size_t lds = ((size_t)a->lds_words + a->lds_read_words + SWMI_TB_REFWIN_WORDS +
+                        (size_t)SWMI_TB_BLOCKS * SWMI_RMAX * WAVE) * sizeof(uint32_t);
+    hipLaunchKernelGGL(sw_traceback_kernel, dim3(a->n_pairs, SWMI_TB_SLOTS), dim3(WAVE), lds, st, *a);
     return hipGetLastError();
 }

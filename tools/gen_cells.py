@@ -1,0 +1,133 @@
+#!/usr/bin/env python3
+"""Generates sparksmithwaterman_amd/csrc/swmi_cells_gen.inc: the hand-scheduled gfx950 instruction
+stream that updates the R cells a lane owns in one anti-diagonal step of the fill kernel.
+
+Per cell (ACGT variant) 9 VALU instructions:
+    v_bfe_i32     a, q, rb, 8            s(ref,read) looked up in the row's 4-entry score profile
+    v_add_u32     a, a, diag             a = NW + s
+    v_cmp_ge_i32  sI, up, left           insertion beats deletion?   (v_cmp_gt for the DistributedSW order)
+    v_max_i32     t, up, left
+    v_add_u32     t, gap, t              t = max(N, W) + gap
+    v_cmp_ge_i32  sA, a, t               alignment beats both?       (v_cmp_gt for the DistributedSW order)
+    v_addc_co_u32 acc, vcc, acc, acc, sI   acc = 2*acc + bit  (compare mask used directly as carry-in)
+    v_max3_i32    hout, a, t, 0          (not in place: the previous column's H stays readable for one more step,
+                                          which lets the tied-maximum check be deferred instead of stalling on it)
+    v_addc_co_u32 acc, vcc, acc, acc, sA
+gfx950 needs 2 wait states between a VALU that writes an SGPR pair and a VALU that reads it; the rows
+are interleaved so every compare has at least two independent instructions before its v_addc, and the
+script checks that distance (inserting s_nop only where a variant cannot avoid it).
+
+The generic variant (any byte alphabet, or scores outside int8) replaces the profile lookup by
+v_cmp_eq_u32 + v_cndmask_b32.
+"""
+import os
+import sys
+
+HAZARD = 2   # wait states: VALU writes SGPR -> VALU reads that SGPR (gfx940/gfx950)
+
+
+class Ins:
+    def __init__(self, text, wr=(), rd=()):
+        self.text, self.wr, self.rd = text, tuple(wr), tuple(rd)
+
+
+def schedule(R, acgt, strict):
+    ge = "v_cmp_gt_i32_e64" if strict else "v_cmp_ge_i32_e64"
+    ins = []
+    # phase 1: substitution scores and the diagonal candidates (all from the previous column's values)
+    if acgt:
+        for k in range(R):
+            ins.append(Ins(f"v_bfe_i32 %[a{k}], %[q{k}], %[rb], 8"))
+    else:
+        for k in range(R):
+            ins.append(Ins(f"v_cmp_eq_u32_e64 %[m{k}], %[rb], %[q{k}]", wr=[f"m{k}"]))
+        for k in range(R):
+            ins.append(Ins(f"v_cndmask_b32_e64 %[a{k}], %[vmis], %[vmat], %[m{k}]", rd=[f"m{k}"]))
+    for k in range(R):
+        src = "%[diag]" if k == 0 else f"%[i{k-1}]"
+        ins.append(Ins(f"v_add_u32_e32 %[a{k}], %[a{k}], {src}"))
+    # phase 2: the dependent chain down the lane's rows
+    for k in range(R):
+        up = "%[up]" if k == 0 else f"%[o{k-1}]"
+        ins.append(Ins(f"{ge} %[sI], {up}, %[i{k}]", wr=["sI"]))
+        if k > 0:
+            ins.append(Ins(f"v_addc_co_u32_e64 %[acc{k-1}], vcc, %[acc{k-1}], %[acc{k-1}], %[sA]", rd=["sA"]))
+        ins.append(Ins(f"v_max_i32_e32 %[t], {up}, %[i{k}]"))
+        ins.append(Ins(f"v_add_u32_e32 %[t], %[gap], %[t]"))
+        ins.append(Ins(f"{ge} %[sA], %[a{k}], %[t]", wr=["sA"]))
+        ins.append(Ins(f"v_addc_co_u32_e64 %[acc{k}], vcc, %[acc{k}], %[acc{k}], %[sI]", rd=["sI"]))
+        ins.append(Ins(f"v_max3_i32 %[o{k}], %[a{k}], %[t], 0"))
+    ins.append(Ins(f"v_addc_co_u32_e64 %[acc{R-1}], vcc, %[acc{R-1}], %[acc{R-1}], %[sA]", rd=["sA"]))
+    # hazard pass
+    out = []
+    last_wr = {}
+    for i in ins:
+        need = 0
+        for r in i.rd:
+            if r in last_wr:
+                gap = len(out) - last_wr[r] - 1 + sum(1 for _ in ())
+                # count issued instructions (s_nop N counts N+1 states)
+                states = 0
+                for o in out[last_wr[r] + 1:]:
+                    states += o.states if hasattr(o, "states") else 1
+                need = max(need, HAZARD - states)
+        if need > 0:
+            nop = Ins(f"s_nop {need - 1}")
+            nop.states = need
+            out.append(nop)
+        out.append(i)
+        for r in i.wr:
+            last_wr[r] = len(out) - 1
+    return out
+
+
+def emit(R, acgt, strict):
+    body = schedule(R, acgt, strict)
+    n_valu = sum(1 for i in body if not i.text.startswith("s_nop"))
+    n_nop = len(body) - n_valu
+    lines = []
+    lines.append(f"// R={R} {'ACGT' if acgt else 'GENERIC'} {'STRICT' if strict else 'SERIAL'}: "
+                 f"{n_valu} VALU ({n_valu / R:.1f}/cell), {n_nop} s_nop")
+    lines.append("template <> struct CellsAsm<%d, %s, %s> {" % (R, "true" if acgt else "false", "true" if strict else "false"))
+    lines.append("    static __device__ __forceinline__ void step(const int (&hin)[%d], int (&hout)[%d], uint32_t (&acc)[%d], const int (&q)[%d]," % (R, R, R, R))
+    lines.append("                                                int rb, int diag, int up, int gap, int vmat, int vmis) {")
+    lines.append("        int " + ", ".join(f"a{k}" for k in range(R)) + ", t;")
+    sg = ["sI", "sA"] + ([] if acgt else [f"m{k}" for k in range(R)])
+    lines.append("        unsigned long long " + ", ".join(sg) + ";")
+    lines.append("        asm volatile(")
+    for i in body:
+        lines.append(f'            "{i.text}\\n\\t"')
+    outs = [f'[o{k}] "=&v"(hout[{k}])' for k in range(R)] + [f'[acc{k}] "+v"(acc[{k}])' for k in range(R)]
+    outs += [f'[a{k}] "=&v"(a{k})' for k in range(R)] + ['[t] "=&v"(t)'] + [f'[{s}] "=&s"({s})' for s in sg]
+    ins_ = [f'[i{k}] "v"(hin[{k}])' for k in range(R)] + [f'[q{k}] "v"(q[{k}])' for k in range(R)] + ['[rb] "v"(rb)', '[diag] "v"(diag)', '[up] "v"(up)', '[gap] "s"(gap)']
+    if not acgt:
+        ins_ += ['[vmat] "v"(vmat)', '[vmis] "v"(vmis)']
+    lines.append("            : " + ", ".join(outs))
+    lines.append("            : " + ", ".join(ins_))
+    lines.append('            : "vcc");')
+    if acgt:
+        lines.append("        (void)vmat; (void)vmis;")
+    lines.append("    }")
+    lines.append("};")
+    return "\n".join(lines)
+
+
+def main():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, "sparksmithwaterman_amd", "csrc", "swmi_cells_gen.inc")
+    parts = ["// GENERATED by tools/gen_cells.py -- do not edit; re-run the script instead.",
+             "// Direction bits pushed per cell: first bI (insertion >= deletion), then bA (alignment >= both):",
+             "// the 2-bit code is (bI << 1) | bA; traceback decodes A if bit0, else I if bit1, else D.",
+             "template <int R, bool ACGT, bool STRICT> struct CellsAsm;", ""]
+    for R in (1, 2, 3, 4):
+        for acgt in (True, False):
+            for strict in (False, True):
+                parts.append(emit(R, acgt, strict))
+                parts.append("")
+    with open(path, "w") as f:
+        f.write("\n".join(parts))
+    print("wrote", path)
+
+
+if __name__ == "__main__":
+    sys.exit(main())
