@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -92,6 +93,7 @@ struct swmi_ctx {
     uint64_t max_workspace_bytes = 32ull << 30;
     int profiling = 0;
     uint64_t arena_words_per_pair = 48;     // first guess of the record arena, grows on demand
+    uint64_t arena_copy_wpp = 48;           // arena words per pair fetched with the first D2H (tracks the last run)
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
@@ -357,6 +359,7 @@ struct RunState {
     TraceArgs ta{};
     float fill_ms = 0, tb_ms = 0, d2h_ms = 0;
     uint32_t launches = 0;
+    double enqueue_us = 0, wait_us = 0, copyout_us = 0;
 };
 
 // layout of the device result block: [ArenaHdr | PairOut x np | arena words ...]
@@ -432,6 +435,7 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
     if ((lds_words + lds_read_words) * 4ull > 128 * 1024)
         return fail(SWMI_ERR_UNSUPPORTED, "a pair of %u bases in total does not fit the traceback's LDS staging", max_path);
 
+    const auto c0 = std::chrono::steady_clock::now();
     uint64_t arena_cap = std::max<uint64_t>(np * ctx->arena_words_per_pair, 1024);
     std::vector<uint8_t> saved_outs;       // PairOut block carried across an arena re-allocation
     for (int attempt = 0;; attempt++) {
@@ -457,10 +461,12 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
         fa.cells_cap = cells_exact ? b->d_cells_cap.as<uint32_t>() : nullptr;
         fa.hdr = (ArenaHdr *)res;
         fa.dbg = nullptr;
+        fa.dbg_pad = 0;
         if (getenv("SWMI_DEBUG_FILL")) {        // diagnostics: per-pair slow-path entries and wave cycles
             if ((rc = b->d_dbg.reserve(np * 16))) return rc;
             fa.dbg = b->d_dbg.as<unsigned long long>();
             fa.dbg_thr0 = getenv("SWMI_DEBUG_THR0") ? (uint32_t)atoi(getenv("SWMI_DEBUG_THR0")) : 1u;
+            fa.dbg_pad = getenv("SWMI_DEBUG_SKIP") ? 1u : 0u;
         }
         fa.n_pairs = (uint32_t)np;
         fa.cell_cap = ctx->cell_cap;
@@ -495,12 +501,18 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
         HIP_TRY(swmi_launch_traceback(&ta, ctx->stream));
         if (ctx->profiling) HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
 
-        // one D2H of header + pair outputs + the whole arena guess
-        const size_t copy_bytes = a_off + arena_cap * 4;
-        if ((rc = b->h_result.reserve(copy_bytes))) return rc;
+        // one D2H of header + pair outputs + as much of the arena as the previous run used (plus slack);
+        // the rare remainder is fetched after the header has been read
+        const uint64_t copy_words = std::min<uint64_t>(arena_cap, std::max<uint64_t>(256, np * ctx->arena_copy_wpp));
+        const size_t copy_bytes = a_off + copy_words * 4;
+        if ((rc = b->h_result.reserve(a_off + arena_cap * 4))) return rc;
         HIP_TRY(hipMemcpyAsync(b->h_result.p, res, copy_bytes, hipMemcpyDeviceToHost, ctx->stream));
         if (ctx->profiling) HIP_TRY(hipEventRecord(ctx->ev[4], ctx->stream));
+        const auto c1 = std::chrono::steady_clock::now();
         HIP_TRY(hipStreamSynchronize(ctx->stream));
+        const auto c2 = std::chrono::steady_clock::now();
+        rs.enqueue_us += std::chrono::duration<double, std::micro>(c1 - c0).count();
+        rs.wait_us += std::chrono::duration<double, std::micro>(c2 - c1).count();
         if (ctx->profiling) {
             float ms = 0;
             if (attempt == 0) { HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1])); rs.fill_ms += ms; }
@@ -536,9 +548,14 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
             continue;
         }
         arena_used = hdr->used_words;
+        if (arena_used > copy_words)
+            HIP_TRY(hipMemcpy((uint8_t *)b->h_result.p + copy_bytes, res + copy_bytes, (arena_used - copy_words) * 4,
+                              hipMemcpyDeviceToHost));
+        ctx->arena_copy_wpp = arena_used * 5 / (4 * np) + 2;
         outs.assign((const PairOut *)(h + result_out_off()), (const PairOut *)(h + result_out_off()) + np);
         arena_copy.assign((const uint32_t *)(h + a_off), (const uint32_t *)(h + a_off) + arena_used);
         for (auto &o : outs) o.flags &= ~SWMI_F_ARENA_OVF;
+        rs.copyout_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - c2).count();
         return SWMI_OK;
     }
 }
@@ -579,6 +596,12 @@ extern "C" int swmi_batch_run(swmi_ctx *ctx, swmi_batch *b, const swmi_params *p
     if (p->types[0] == p->types[1] || p->types[0] == p->types[2] || p->types[1] == p->types[2])
         return fail(SWMI_ERR_UNSUPPORTED, "alignTypes a/i/d must be pairwise distinct");
     std::lock_guard<std::mutex> g(ctx->mu);
+    const bool host_dbg = getenv("SWMI_DEBUG_HOST") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point c) {
+        return std::chrono::duration<double, std::micro>(c - a).count();
+    };
+    const auto h0 = now();
     HIP_TRY(hipSetDevice(ctx->device));
     b->params = *p;
     b->has_run = false;
@@ -613,6 +636,7 @@ extern "C" int swmi_batch_run(swmi_ctx *ctx, swmi_batch *b, const swmi_params *p
     // longest first: the tail of the launch is made of short pairs
     std::stable_sort(work.begin(), work.end(), [](const Work &a, const Work &c) { return a.cells > c.cells; });
 
+    const auto h1 = now();
     RunState rs;
     rs.ctx = ctx; rs.b = b;
     hipEvent_t ev_total0 = ctx->ev[5];
@@ -649,6 +673,7 @@ extern "C" int swmi_batch_run(swmi_ctx *ctx, swmi_batch *b, const swmi_params *p
         lo = hi;
     }
 
+    const auto h2 = now();
     // pairs with more tied cells than cell_cap: run them again on the GPU with exact-size lists
     if (!ovf.empty()) {
         std::vector<Work> w2;
@@ -710,6 +735,9 @@ extern "C" int swmi_batch_run(swmi_ctx *ctx, swmi_batch *b, const swmi_params *p
     b->timing.cells = total_cells;
     b->timing.dir_bytes = dir_bytes;
     b->has_run = true;
+    if (host_dbg)
+        fprintf(stderr, "[swmi host] setup %.1f us, chunks (launch+wait+parse) %.1f us [enqueue %.1f, wait %.1f, copy-out %.1f], grouping %.1f us\n",
+                us(h0, h1), us(h1, h2), rs.enqueue_us, rs.wait_us, rs.copyout_us, us(h2, now()));
     return SWMI_OK;
 }
 

@@ -113,22 +113,29 @@ record_max_cells(int h0, int h1, int h2, int h3, uint32_t t, uint32_t lane_eff, 
     const int hh[4] = {h0, h1, h2, h3};
     const uint32_t c0 = t - lane_eff;                  // column index j-1 the lane worked on at step t
     const bool active = c0 < n;
+    int v[R];
     int cand = -1;
 #pragma unroll
-    for (int k = 0; k < R; ++k)
-        if (active && row0 + k < m) cand = cand > hh[k] ? cand : hh[k];
-    const int wmax = wave_max_i32(cand);
-    if (wmax >= thr) {
-        if (wmax > thr) { thr = wmax; cnt = 0; }        // SmithWaterman.java:176-181
+    for (int k = 0; k < R; ++k) {
+        v[k] = (active && row0 + k < m) ? hh[k] : -1;   // rows past the read and lanes off their range never count
+        cand = cand > v[k] ? cand : v[k];
+    }
+    if (__ballot(cand >= thr) == 0) return ((unsigned long long)(uint32_t)thr << 32) | cnt;   // stale trigger
+    // strict increase: climb to the wave's maximum by lane hops (no reduction network needed: few lanes exceed)
+    uint64_t gt = __ballot(cand > thr);
+    while (gt) {                                        // SmithWaterman.java:176-181
+        thr = __builtin_amdgcn_readlane(cand, (int)__builtin_ctzll(gt));
+        cnt = 0;
+        gt = __ballot(cand > thr);
+    }
 #pragma unroll
-        for (int k = 0; k < R; ++k) {
-            const bool hit = active && (row0 + k < m) && (hh[k] == thr);   // :182-185
-            const uint64_t hm = __ballot(hit);
-            if (hm) {
-                const uint32_t pos = cnt + lanemask_lt_count(hm);
-                if (hit && pos < ccap) cells[pos] = make_uint2(row0 + k + 1, c0 + 1u);
-                cnt += (uint32_t)__popcll(hm);
-            }
+    for (int k = 0; k < R; ++k) {
+        const bool hit = v[k] == thr;                   // :182-185
+        const uint64_t hm = __ballot(hit);
+        if (hm) {
+            const uint32_t pos = cnt + lanemask_lt_count(hm);
+            if (hit && pos < ccap) cells[pos] = make_uint2(row0 + k + 1, c0 + 1u);
+            cnt += (uint32_t)__popcll(hm);
         }
     }
     return ((unsigned long long)(uint32_t)thr << 32) | cnt;
@@ -150,11 +157,17 @@ struct FillState {
     uint32_t cnt;        // wave-uniform number of cells equal to thr
     uint64_t ev_prev;    // lanes whose previous step reached thr (handled one step late, see below)
     uint32_t events;     // slow-path entries (diagnostics only)
+    bool dbg_skip;       // diagnostics only
 };
 
 template <int R>
 __device__ __forceinline__ void handle_pending(FillState<R> &S, const int (&hv)[R], uint32_t t, uint32_t lane_eff,
                                                uint32_t n, uint32_t row0, uint32_t m, uint2 *__restrict__ cells, uint32_t ccap) {
+    if (S.dbg_skip) {          // diagnostics: price of the branch alone (results are wrong in this mode)
+        S.events++;
+        S.thr += 1;
+        return;
+    }
     const unsigned long long tc = record_max_cells<R>(
         hv[0], R > 1 ? hv[R > 1 ? 1 : 0] : 0, R > 2 ? hv[R > 2 ? 2 : 0] : 0, R > 3 ? hv[R > 3 ? 3 : 0] : 0,
         t, lane_eff, n, row0, m, S.thr, S.cnt, cells, ccap);
@@ -215,7 +228,7 @@ __device__ __forceinline__ void fill_block16(FillState<R> &S, const uint4 w, con
             if (MULTI && feeds_seam && lane == WAVE - 1) seam_out[t0 + s - lane + 1] = hout[R - 1];
         }
         S.nprev = nin;
-        const uint64_t ev = __ballot(mrow >= S.thr);
+        const uint64_t ev = __ballot(mrow >= S.thr);      // all 64 lanes vote: thr / cnt stay wave-uniform
         if (__builtin_expect(S.ev_prev != 0, 0))                           // step t0+s-1, values still in hin
             handle_pending<R>(S, hin, t0 + s - 1u, lane_eff, n, row0, m, cells, ccap);
         S.ev_prev = ev;
@@ -245,6 +258,7 @@ __device__ __forceinline__ void fill_pair(const FillArgs &A, const PairDesc pd, 
     S.cnt = 0;
     S.ev_prev = 0;
     S.events = 0;
+    S.dbg_skip = A.dbg && (A.dbg_pad != 0);
     const unsigned long long t_start = A.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
 
     for (uint32_t s = 0; s < n_strips; ++s) {
@@ -476,12 +490,18 @@ __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDes
                     const uint32_t lx = rx / R, kx = rx - lx * R;
                     const int tx = (int)(j - lane) - 1 + (int)lx;
                     const bool valid = rho_x >= 0 && j > lane && tx >= tmin;
+                    // all three LDS reads are issued together (one latency): direction word, reference code, read code
                     uint32_t d = 0;
+                    bool mt = false;
                     if (valid) {
                         const uint32_t dw = lds_tile[(((uint32_t)tx >> 4) - wlo) * (R * WAVE) + kx * WAVE + lx];
+                        const uint32_t rc = ref_b[(j - 1u - lane) - 4u * cw0];
+                        const uint32_t qc = read_b[i - 1u - lane];
                         d = (dw >> (2u * (15u - ((uint32_t)tx & 15u)))) & 3u;
+                        mt = rc == qc;
                     }
-                    if (!(__ballot(valid) & 1ull)) break;                          // current cell left the tile / the strip: restage
+                    const uint64_t vmask = __ballot(valid);
+                    if (!(vmask & 1ull)) break;                                    // current cell left the tile / the strip: restage
                     const uint64_t amask = __ballot(valid && (d & 1u));
                     uint32_t run = ~amask == 0ull ? 64u : (uint32_t)__builtin_ctzll(~amask);
                     if (run == 0) {
@@ -495,8 +515,6 @@ __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDes
                         n_ops += 1u;
                     } else {
                         // a run of alignment moves: H(i-1,j-1) = H - s(ref[j-1], read[i-1])   (:388-394)
-                        bool mt = false;
-                        if (lane < run) mt = ref_b[(j - 1u - lane) - 4u * cw0] == read_b[i - 1u - lane];
                         const uint64_t mm = __ballot(mt);
                         const uint32_t cm = lanemask_lt_count(mm) + (mt ? 1u : 0u);          // matches among lanes 0..x
                         const uint32_t after = score - (cm * umat + (lane + 1u - cm) * umis);   // H after x+1 moves
