@@ -41,6 +41,8 @@ static int fail(int code, const char *fmt, ...) {
     return code;
 }
 
+int swmi_io_fail(int code, const std::string &msg) { return fail(code, "%s", msg.c_str()); }
+
 #define HIP_TRY(expr)                                                                         \
     do {                                                                                      \
         hipError_t e_ = (expr);                                                               \

@@ -127,3 +127,81 @@ class Distribution:
 
         def result(self):
             return self.max, sorted(self.opt, key=lambda v: v[0][0])
+
+
+# ------------------------------------------------------------------------------------------------
+# file-level drivers: same positional ioArgs / algoArgs as the reference
+# ------------------------------------------------------------------------------------------------
+import time as _time
+
+from . import io as _io
+
+
+class _FileDriver:
+    """Shared body of the two drivers below.  ioArgs = [refDir, inDir, delimiter, outDir, outName, outExt]
+    (nulls keep the defaults, Distribution.java:267-281); algoArgs = (alignScores, alignTypes) or None (:284-292)."""
+
+    OUT_FILE, OUT_EXT = "result", ".txt"                              # Distribution.java:40-41
+    REF_DIR, IN_DIR = "/home/ubuntu/project/reference", "/home/ubuntu/project/input"   # :43-44
+    OUT_DIR = "/home/ubuntu/project/output/reference"                 # :50
+
+    def __init__(self, context=None, tie_mode=_capi.TIE_SERIAL):
+        self._ctx = context
+        self._tie = tie_mode
+
+    def call(self, ioArgs=None, algoArgs=None):
+        ref_dir, in_dir, delim = self.REF_DIR, self.IN_DIR, _io.DELIMITER
+        out_dir, out_name, out_ext = self.OUT_DIR, self.OUT_FILE, self.OUT_EXT
+        if ioArgs is not None and len(ioArgs) == 6:
+            ref_dir = ioArgs[0] if ioArgs[0] is not None else ref_dir
+            in_dir = ioArgs[1] if ioArgs[1] is not None else in_dir
+            delim = ioArgs[2] if ioArgs[2] is not None else delim
+            out_dir = ioArgs[3] if ioArgs[3] is not None else out_dir
+            out_name = ioArgs[4] if ioArgs[4] is not None else out_name
+            out_ext = ioArgs[5] if ioArgs[5] is not None else out_ext
+        sc, ty = _algo(*(algoArgs if algoArgs is not None else (None, None)))
+        ctx = self._ctx or default_context()
+        params = make_params(sc, ty, self._tie)
+
+        in_crawl = _io.DirectoryCrawler(in_dir)
+        input_num = 0
+        while in_crawl.hasNext():
+            input_num += 1
+            reads = _io.InOutOps.GetReads().call(in_crawl.next(), delim)
+            num_refs = 0
+            t0 = _time.time()
+            red = Distribution.ReduceMax()                       # `int max = 0` + ties, Distribution.java:573,600-613
+            ref_crawl = _io.DirectoryCrawler(ref_dir)
+            while ref_crawl.hasNext():
+                rs = _io.read_refs_packed(ref_crawl.next(), delim)
+                num_refs += len(rs)
+                seqs = rs.sequences()
+                b = ctx.upload(seqs, reads).run(params)          # every reference of the file x every read: one batch
+                try:
+                    for r in range(len(rs)):
+                        total = b.ref_total(r)
+                        if total >= red.max:                     # match sites are only materialised for candidates
+                            red.add(total, ([rs.metadata[r], seqs[r]], b.ref_match_sites(r)))
+                finally:
+                    b.free()
+            exec_ms = int((_time.time() - t0) * 1000)
+            mx, opt = red.result()                               # Collections.sort(opt, new OptSeqsComp())  :621
+            text = _io.InOutOps.GetOutputStr().call(reads, ((num_refs, len(reads)), mx, exec_ms), opt)
+            _io.InOutOps.PrintStrToFile().call("%s/%s%d%s" % (out_dir, out_name, input_num, out_ext), text)
+        return None
+
+
+class _NoDistribution(_FileDriver):
+    """Distribution.NoDistribution.call (Distribution.java:482-634), alignments on the GPU."""
+    OUT_DIR = "/home/ubuntu/project/output/control"               # :49
+
+
+class _DistributeReference(_FileDriver):
+    """Distribution.DistributeReference.call (Distribution.java:227-373) with the control path's reduce.
+
+    The reference's own reduce (`sortByKey` result discarded, then `first()`, :341-342) reports the FIRST
+    reference's total instead of the maximum; the intended semantics (running max with ties, :600-613) are used."""
+
+
+Distribution.NoDistribution = _NoDistribution
+Distribution.DistributeReference = _DistributeReference

@@ -1,0 +1,135 @@
+"""Native sequence-file reader and result writer against the Python restatement of InOutOps (CPU only),
+and the file-level drivers end to end on the GPU."""
+import os
+
+import pytest
+
+import sparksmithwaterman_amd as sw
+from sparksmithwaterman_amd import io as swio
+from oracle import io_oracle_py as ioo
+
+REF = "CCTGGGTCCTGCCTCGCATCTGACCAGGGCAGGTGGCCTCCTCATCACACTGCTGCCTCTGCTGTTGGCCCTGCTCATGA"   # EngineerData.java:23
+READ_20 = "ACTGACTGACTGACTGACTG"                                                            # EngineerData.java:29
+
+CASES = {
+    "plain.fa": ">gi|1 first\nACGTACGT\nACGT\n>gi|2 second\nGGGGCCCC\n",
+    "crlf.fa": ">gi|1\r\nACGT\r\nAC GT \r\n>gi|2\r\n\r\nTT\r\n",
+    "noeol.fa": ">gi|a\nAC\n>gi|b\nGT",
+    "untrimmed.fa": ">gi|x meta with spaces  \n  ACGT  \n\tAC\n>gi|y\n>gi|z\nA\n",
+    "lonecr.fa": ">gi|1\rACGT\rAC\r",
+    "reads_meta.txt": ">gi|reads file\nACGT\n\n  AC GT  \n>gi|not skipped\nTTTT",
+    "reads_nometa.txt": "ACGTAC\nGG\n",
+    "reads_oneline.txt": ">gi only metadata",
+}
+
+
+@pytest.fixture(scope="module")
+def files(tmp_path_factory):
+    d = tmp_path_factory.mktemp("seqfiles")
+    for name, text in CASES.items():
+        with open(d / name, "w", newline="") as f:
+            f.write(text)
+    return d
+
+
+def test_io_symbols_exported():
+    lib = sw._capi.load()
+    for name, _, _ in swio.IO_SYMBOLS:
+        assert getattr(lib, name) is not None
+
+
+@pytest.mark.parametrize("name", [n for n in CASES if n.endswith(".fa")])
+def test_get_ref_seqs_matches_restatement(files, name):
+    got = swio.InOutOps.GetRefSeqs().call(files / name, ">gi")
+    assert got == ioo.get_ref_seqs(files / name, ">gi")
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_get_reads_matches_restatement(files, name):
+    got = swio.InOutOps.GetReads().call(files / name, ">gi")
+    assert got == ioo.get_reads(files / name, ">gi")
+
+
+def test_reads_quirks_spelled_out(files):
+    # every line after the first is a read: blank lines and later '>' lines included (InOutOps.java:75-76)
+    assert swio.InOutOps.GetReads().call(files / "reads_meta.txt", ">gi") == ["ACGT", "", "AC GT", ">gi|not skipped", "TTTT"]
+    assert swio.InOutOps.GetReads().call(files / "reads_oneline.txt", ">gi") == []
+    # reference lines are appended untrimmed (:148); an empty record is kept
+    assert swio.InOutOps.GetRefSeqs().call(files / "untrimmed.fa", ">gi") == [
+        [">gi|x meta with spaces  ", "  ACGT  \tAC"], [">gi|y", ""], [">gi|z", "A"]]
+
+
+def test_reader_errors(files, tmp_path):
+    empty = tmp_path / "empty.txt"
+    empty.write_text("")
+    with pytest.raises(sw.SwmiError):
+        swio.InOutOps.GetReads().call(empty, ">gi")
+    with pytest.raises(sw.SwmiError):
+        swio.InOutOps.GetRefSeqs().call(empty, ">gi")
+    with pytest.raises(sw.SwmiError):
+        swio.InOutOps.GetRefSeqs().call(files / "reads_nometa.txt", ">gi")     # no leading metadata line
+    with pytest.raises(sw.SwmiError):
+        swio.InOutOps.GetReads().call(tmp_path / "missing.txt", ">gi")
+
+
+def test_packed_reader_feeds_offsets(files):
+    s = swio.read_refs_packed(files / "plain.fa", ">gi")
+    assert len(s) == 2 and s.offsets == [0, 12, 20] and s.blob == b"ACGTACGTACGTGGGGCCCC"
+    assert s.metadata == [">gi|1 first", ">gi|2 second"]
+
+
+def test_output_str_matches_restatement():
+    reads = ["ACGT", ""]
+    opt = [([">gi|b", "ACGTT"], [(1, ("ACGT", "ACGT")), (3, ("G_T", "GAT"))]), ([">gi|a", "AC"], [])]
+    got = swio.InOutOps.GetOutputStr().call(reads, ((7, 2), 20, 123), opt)
+    assert got == ioo.get_output_str(reads, (7, 2), 20, 123, opt)
+    nl = os.linesep
+    assert got.startswith("Execution Time = 123 ms" + nl + nl + "# Reference Sequences = 7" + nl + "# Reads = 2" + nl + nl + "Input:" + nl)
+    assert ("Maximum alignment score = 20" + nl + "Reference:" + nl + ">gi|b" + nl + "ACGTT" + nl + nl + "\tIndex = 1" + nl) in got
+
+
+def test_directory_crawler_depth_first(tmp_path):
+    (tmp_path / "b").mkdir()
+    (tmp_path / "b" / "z.txt").write_text("x")
+    (tmp_path / "a.txt").write_text("x")
+    (tmp_path / "c.txt").write_text("x")
+    c = swio.DirectoryCrawler(str(tmp_path))
+    seen = []
+    while c.hasNext():
+        seen.append(os.path.relpath(c.next(), tmp_path))
+    assert seen == ["a.txt", os.path.join("b", "z.txt"), "c.txt"]
+    with pytest.raises(FileNotFoundError):
+        swio.DirectoryCrawler(str(tmp_path / "nope"))
+
+
+@pytest.mark.gpu
+def test_drivers_write_the_control_drivers_result_files(tmp_path):
+    ref_dir, in_dir = tmp_path / "reference", tmp_path / "input"
+    out_gpu, out_cpu = tmp_path / "out_gpu", tmp_path / "out_cpu"
+    for d in (ref_dir, in_dir, out_gpu, out_cpu, ref_dir / "sub"):
+        d.mkdir()
+    # EngineerData-shaped files: references are REF repeated (EngineerData.java:118,139), 80 characters per line
+    def fasta(recs):
+        out = []
+        for meta, seq in recs:
+            out.append(meta)
+            out.extend(seq[k:k + 80] for k in range(0, len(seq), 80))
+        return "\n".join(out) + "\n"
+    (ref_dir / "ref1.fa").write_text(fasta([(">gi|ref1", REF * 3), (">gi|ref0", REF[::-1] * 2), (">gi|ref2", REF * 3)]))
+    (ref_dir / "sub" / "ref9.fa").write_text(fasta([(">gi|ref9", REF[5:70] + "ACGT" * 9)]))
+    (in_dir / "input1.txt").write_text(">gi reads\n" + REF[10:50] + "\n" + READ_20 + "\n")
+    (in_dir / "input2.txt").write_text("TTTTTTTTGGGGG\n")
+    ctx = sw.Context(0)
+    io_args = [str(ref_dir), str(in_dir), ">gi", str(out_gpu), None, None]
+    assert sw.Distribution.DistributeReference(ctx).call(io_args, None) is None
+    expect = ioo.no_distribution(str(ref_dir), str(in_dir), ">gi", str(out_cpu))
+    for k, text in enumerate(expect, 1):
+        got = open(out_gpu / ("result%d.txt" % k), newline="").read()
+        # identical apart from the wall-clock line (InOutOps.java:249)
+        assert got.split(os.linesep, 1)[1] == text.split(os.linesep, 1)[1]
+        assert got.startswith("Execution Time = ")
+    out2 = tmp_path / "out_ctl"
+    out2.mkdir()
+    sw.Distribution.NoDistribution(ctx).call([str(ref_dir), str(in_dir), ">gi", str(out2), "res", ".out"], ([5, -3, -4], ["a", "i", "d", "-"]))
+    assert open(out2 / "res1.out", newline="").read().split(os.linesep, 1)[1] == expect[0].split(os.linesep, 1)[1]
+    ctx.close()
