@@ -35,6 +35,8 @@ def main():
     ap.add_argument("--ref-len", type=int, default=2000)
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fuse", action="store_true", help="mode 1 as ONE launch (sweep + replay + walk per wavefront)")
+    ap.add_argument("--mode", type=int, default=None, help="kernel pipeline: 1 = score-only sweep + replay (default), 0 = HBM direction field")
     args = ap.parse_args()
 
     import torch
@@ -67,6 +69,12 @@ def main():
 
     ctx = sw.Context(local_rank)
     ctx.set_option("profiling", 1)
+    if args.mode is not None:
+        ctx.set_option("mode", args.mode)
+    if args.fuse:
+        ctx.set_option("fuse", 1)
+    mode = 1 if args.mode is None else args.mode
+    kernel_name = "sw_fill_kernel" if mode == 0 else ("sw_align_fused_kernel" if args.fuse else "sw_fill_score_kernel")
     batch = ctx.upload(refs, reads)          # H2D happens here, outside the timed region
     params = sw.make_params()
 
@@ -128,7 +136,7 @@ def main():
                                       % (world, "over RCCL" if world > 1 else "local")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "kernel": "sw_fill_kernel", "kernel_avg_ms": round(fill_avg_s * 1e3, 4),
+                         "kernel": kernel_name, "kernel_avg_ms": round(fill_avg_s * 1e3, 4),
                          "alg_bytes_per_launch": bytes_rank,
                          "kernel_gcups": round(cells_rank / fill_avg_s / 1e9, 2) if fill_avg_s > 0 else None,
                          "traceback_avg_ms": round(tb_ms / args.steps, 4), "d2h_avg_ms": round(d2h_ms / args.steps, 4)},

@@ -77,8 +77,12 @@ void        swmi_default_params(swmi_params *p);
 
 /* Tuning knobs (all optional).  cell_cap: tied-maximum cells kept per pair in the
  * fast path (pairs with more are re-run on the GPU with an exact-size list);
- * max_workspace_bytes: cap on the direction-field arena (larger batches are run in
- * chunks); profiling != 0 brackets every kernel with HIP events. */
+ * max_workspace_bytes: cap on the per-batch workspace arena (larger batches are run in
+ * chunks); profiling != 0 brackets every kernel with HIP events; mode: 1 (default) = the
+ * fill sweeps scores only and leaves lane-state checkpoints, the traceback re-sweeps the
+ * 64-step windows a path crosses with direction bits into LDS; 0 = the fill writes the whole
+ * 2-bit direction field to HBM and the traceback reads it (cheaper when most pairs have many
+ * tied maxima).  Results are identical in both modes. */
 int         swmi_set_option(swmi_ctx *ctx, const char *name, int64_t value);
 
 /* ---- staged path: upload once, run many times (what bench.py times) ------------- */

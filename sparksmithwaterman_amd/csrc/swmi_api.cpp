@@ -25,6 +25,7 @@
 
 extern "C" hipError_t swmi_launch_fill(const FillArgs *a, hipStream_t st);
 extern "C" hipError_t swmi_launch_traceback(const TraceArgs *a, hipStream_t st);
+extern "C" hipError_t swmi_launch_fused(const FusedArgs *a, hipStream_t st);
 
 // ------------------------------------------------------------------------------------------
 // errors
@@ -94,6 +95,9 @@ struct swmi_ctx {
     uint32_t cell_cap = 64;
     uint64_t max_workspace_bytes = 32ull << 30;
     int profiling = 0;
+    uint32_t mode = 1;                      // 0 = direction field in HBM, 1 = score-only sweep + checkpointed replay
+    int fuse = 0;                           // mode 1: sweep and walk in one launch (off: measured slower whenever some pairs
+                                            // have several tied maxima, because their walks then serialise on one wavefront)
     uint64_t arena_words_per_pair = 48;     // first guess of the record arena, grows on demand
     uint64_t arena_copy_wpp = 48;           // arena words per pair fetched with the first D2H (tracks the last run)
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -118,6 +122,13 @@ struct PairRes {
 
 struct SiteRef { uint64_t pair; uint64_t k; int32_t begin; };
 
+struct Work {            // one pair scheduled for a launch
+    uint32_t pair;       // ref * n_reads + read
+    uint64_t cells;      // m * n
+    uint64_t dir_words;  // workspace dwords (direction field or checkpoints)
+    uint64_t seam_words;
+};
+
 struct swmi_batch {
     uint32_t n_refs = 0, n_reads = 0;
     // original bytes (for string building: characters keep their case) and offsets
@@ -130,6 +141,9 @@ struct swmi_batch {
     // per run
     swmi_params params{};
     bool has_run = false;
+    std::vector<Work> work;                 // schedule (pairs sorted by work), valid for work_mode
+    int work_mode = -1;
+    uint64_t work_cells = 0;
     std::vector<uint8_t> pairs_on_device;   // image of the PairDesc array currently in d_pairs
     const void *pairs_dev_ptr = nullptr;
     std::vector<PairRes> pairs;             // by pair index
@@ -212,6 +226,11 @@ extern "C" int swmi_set_option(swmi_ctx *ctx, const char *name, int64_t value) {
     } else if (!strcmp(name, "max_workspace_bytes")) {
         if (value < (1 << 20)) return fail(SWMI_ERR_INVALID, "max_workspace_bytes too small");
         ctx->max_workspace_bytes = (uint64_t)value;
+    } else if (!strcmp(name, "mode")) {
+        if (value != 0 && value != 1) return fail(SWMI_ERR_INVALID, "mode must be 0 or 1");
+        ctx->mode = (uint32_t)value;
+    } else if (!strcmp(name, "fuse")) {
+        ctx->fuse = value != 0;
     } else if (!strcmp(name, "profiling")) {
         ctx->profiling = value != 0;
     } else if (!strcmp(name, "arena_words_per_pair")) {
@@ -347,13 +366,6 @@ extern "C" int swmi_batch_upload(swmi_ctx *ctx,
 // ------------------------------------------------------------------------------------------
 namespace {
 
-struct Work {            // one pair scheduled for a launch
-    uint32_t pair;       // ref * n_reads + read
-    uint64_t cells;      // m * n
-    uint64_t dir_words;
-    uint64_t seam_words;
-};
-
 struct RunState {
     swmi_ctx *ctx;
     swmi_batch *b;
@@ -474,6 +486,8 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
         fa.cell_cap = ctx->cell_cap;
         fa.match = b->params.match; fa.mismatch = b->params.mismatch; fa.gap = b->params.gap;
         fa.strict = b->params.tie_mode == SWMI_TIE_STRICT;
+        fa.mode = ctx->mode;
+        fa.pad2 = 0;
 
         TraceArgs &ta = rs.ta;
         ta.seqw = fa.seqw; ta.refs = fa.refs; ta.reads = fa.reads; ta.pairs = fa.pairs;
@@ -485,6 +499,9 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
         ta.n_pairs = fa.n_pairs; ta.cell_cap = fa.cell_cap;
         ta.match = fa.match; ta.mismatch = fa.mismatch; ta.gap = fa.gap; ta.strict = fa.strict;
         ta.lds_words = lds_words;
+        ta.seam = fa.seam;
+        ta.mode = ctx->mode;
+        ta.pad2 = 0;
         ta.lds_read_words = lds_read_words;
         ta.dbg = nullptr;
         if (getenv("SWMI_DEBUG_FILL")) {
@@ -493,15 +510,29 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
             ta.dbg = b->d_dbg2.as<unsigned long long>();
         }
 
-        if (attempt == 0) {       // the direction field survives an arena-overflow retry
+        const bool fused = ctx->mode == 1 && ctx->fuse && attempt == 0;
+        if (fused) {
+            // one launch: sweep + walk per wavefront.  The arena header is zeroed by a memset node ahead of it
+            // (waves start appending at different times, so no wave of the launch can do it).
+            fa.hdr = nullptr;
+            HIP_TRY(hipMemsetAsync(res, 0, 64, ctx->stream));
+            FusedArgs fu;
+            fu.f = fa; fu.t = ta;
             if (ctx->profiling) HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
-            HIP_TRY(swmi_launch_fill(&fa, ctx->stream));
-            if (ctx->profiling) HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
+            HIP_TRY(swmi_launch_fused(&fu, ctx->stream));
+            if (ctx->profiling) { HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream)); HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream)); HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream)); }
             rs.launches++;
+        } else {
+            if (attempt == 0) {       // the workspace survives an arena-overflow retry
+                if (ctx->profiling) HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
+                HIP_TRY(swmi_launch_fill(&fa, ctx->stream));
+                if (ctx->profiling) HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
+                rs.launches++;
+            }
+            if (ctx->profiling) HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
+            HIP_TRY(swmi_launch_traceback(&ta, ctx->stream));
+            if (ctx->profiling) HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
         }
-        if (ctx->profiling) HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
-        HIP_TRY(swmi_launch_traceback(&ta, ctx->stream));
-        if (ctx->profiling) HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
 
         // one D2H of header + pair outputs + as much of the arena as the previous run used (plus slack);
         // the rare remainder is fetched after the header has been read
@@ -618,26 +649,31 @@ extern "C" int swmi_batch_run(swmi_ctx *ctx, swmi_batch *b, const swmi_params *p
     b->timing = swmi_timing{};
 
     // pairs with an empty side never enter ScoreMatrix's loops (SmithWaterman.java:157-159): (0, [])
-    std::vector<Work> work;
-    work.reserve(n_pairs);
-    uint64_t total_cells = 0;
-    for (uint32_t r = 0; r < n_refs; r++) {
-        const uint32_t n = b->ref_desc[r].len;
-        for (uint32_t q = 0; q < n_reads; q++) {
-            const uint32_t m = b->read_desc[q].len;
-            if (m == 0 || n == 0) continue;
-            Work w;
-            w.pair = r * n_reads + q;
-            w.cells = (uint64_t)m * n;
-            w.dir_words = swmi_dir_words(m, n);
-            w.seam_words = m > 64u * SWMI_RMAX ? 2ull * (n + 1) : 0;
-            total_cells += w.cells;
-            work.push_back(w);
+    // The schedule only depends on the sequence lengths and the pipeline mode: built once per batch.
+    if (b->work_mode != (int)ctx->mode) {
+        b->work.clear();
+        b->work.reserve(n_pairs);
+        b->work_cells = 0;
+        for (uint32_t r = 0; r < n_refs; r++) {
+            const uint32_t n = b->ref_desc[r].len;
+            for (uint32_t q = 0; q < n_reads; q++) {
+                const uint32_t m = b->read_desc[q].len;
+                if (m == 0 || n == 0) continue;
+                Work w;
+                w.pair = r * n_reads + q;
+                w.cells = (uint64_t)m * n;
+                w.dir_words = swmi_dir_words(m, n, ctx->mode);
+                w.seam_words = swmi_seam_words(m, n);
+                b->work_cells += w.cells;
+                b->work.push_back(w);
+            }
         }
+        // longest first: the tail of the launch is made of short pairs
+        std::stable_sort(b->work.begin(), b->work.end(), [](const Work &a, const Work &c) { return a.cells > c.cells; });
+        b->work_mode = (int)ctx->mode;
     }
-    // longest first: the tail of the launch is made of short pairs
-    std::stable_sort(work.begin(), work.end(), [](const Work &a, const Work &c) { return a.cells > c.cells; });
-
+    const std::vector<Work> &work = b->work;
+    const uint64_t total_cells = b->work_cells;
     const auto h1 = now();
     RunState rs;
     rs.ctx = ctx; rs.b = b;

@@ -29,6 +29,7 @@
 
 #define SWMI_SEQ_PAD_WORDS 24u
 #define SWMI_RMAX          4          // rows per lane in the widest kernel variant
+#define SWMI_CK_BLOCKS     2u         // mode 1: a lane-state checkpoint every 2 blocks = 32 anti-diagonal steps
 #define SWMI_CODE_PAD      0x1FFu     // never equals a base code (codes are 0..255)
 
 // op codes of an alignment record (2 bits per traceback step)
@@ -54,7 +55,7 @@ struct PairDesc {
     uint32_t out_id;      // index into out[] / cells[] (the pair's position in the batch)
     uint32_t pad;
     uint64_t dir_off;     // dword offset of this pair's direction field in dir[]
-    uint64_t seam_off;    // dword offset of the 2*(n+1) int32 strip-seam rows (multi-strip pairs only)
+    uint64_t seam_off;    // dword offset of the strip-seam rows, n+1 int32 per strip (multi-strip pairs only)
 };
 
 struct PairOut {
@@ -98,6 +99,8 @@ struct FillArgs {
     uint32_t        cell_cap;
     int32_t         match, mismatch, gap;
     uint32_t        strict;      // tie mode
+    uint32_t        mode;        // 0 = direction field in HBM, 1 = score-only sweep + checkpoints
+    uint32_t        pad2;
 };
 
 struct TraceArgs {
@@ -120,17 +123,29 @@ struct TraceArgs {
     uint32_t        lds_words;   // staging words per block for the ops of one alignment
     uint32_t        lds_read_words;   // LDS dwords reserved for the longest read's codes
     unsigned long long *dbg;     // optional diagnostics: per pair {ticks, walk ticks, steps, tiles}
+    const int32_t  *seam;        // mode 1: strip seam rows for the replay of multi-strip pairs
+    uint32_t        mode;        // 0 = read the HBM direction field, 1 = replay windows from checkpoints
+    uint32_t        pad2;
 };
+
+struct FusedArgs { FillArgs f; TraceArgs t; };
 
 // rows per lane for a read of m bases
 SWMI_HD static inline uint32_t swmi_rows_per_lane(uint32_t m) {
     uint32_t r = (m + 63u) / 64u;
     return r < 1u ? 1u : (r > SWMI_RMAX ? SWMI_RMAX : r);
 }
-// dwords of direction field for one pair
-SWMI_HD static inline uint64_t swmi_dir_words(uint32_t m, uint32_t n) {
+// dwords of per-pair workspace: the direction field (mode 0) or the lane-state checkpoints (mode 1)
+SWMI_HD static inline uint64_t swmi_dir_words(uint32_t m, uint32_t n, uint32_t mode) {
     uint32_t R = swmi_rows_per_lane(m);
     uint64_t strips = ((uint64_t)m + 64u * R - 1u) / (64u * R);
     uint64_t wblocks = ((uint64_t)n + 63u + 15u) / 16u;   // T = n + 63 steps at most
-    return strips * wblocks * R * 64u;
+    if (mode == 0) return strips * wblocks * R * 64u;
+    return strips * ((wblocks + SWMI_CK_BLOCKS - 1u) / SWMI_CK_BLOCKS) * (R + 2u) * 64u;
+}
+// int32 seam rows of a pair whose read spans several strips: one row of n+1 per strip
+SWMI_HD static inline uint64_t swmi_seam_words(uint32_t m, uint32_t n) {
+    if (m <= 64u * SWMI_RMAX) return 0;
+    uint64_t strips = ((uint64_t)m + 64u * SWMI_RMAX - 1u) / (64u * SWMI_RMAX);
+    return strips * ((uint64_t)n + 1u);
 }

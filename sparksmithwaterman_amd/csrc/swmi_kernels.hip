@@ -30,6 +30,10 @@
 #include "swmi_device.h"
 
 #define WAVE 64
+#define BALLOT(pred) __builtin_amdgcn_ballot_w64(pred)
+// LDS hand-offs between lanes of ONE wavefront: DS operations of a wave execute in order, so a compiler-level
+// fence is all that is needed (a workgroup barrier would deadlock the fused kernel's 4 independent waves)
+#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 
 // ------------------------------------------------------------------------------------------------
 // small helpers
@@ -62,6 +66,11 @@ __device__ __forceinline__ uint32_t lanemask_lt_count(uint64_t mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
+// load served by L2 (bypasses this CU's L1): for data another wave -- or this wave, earlier -- stored in the same launch
+__device__ __forceinline__ uint32_t ld_l2(const uint32_t *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __device__ __forceinline__ uint32_t seq_code(const uint32_t *__restrict__ w, uint32_t pos) {
     return (w[pos >> 2] >> (8u * (pos & 3u))) & 0xFFu;
 }
@@ -69,10 +78,10 @@ __device__ __forceinline__ uint32_t seq_code(const uint32_t *__restrict__ w, uin
 // ------------------------------------------------------------------------------------------------
 // the R cells of one lane in one step (previous column's H in hin, this column's H to hout)
 // ------------------------------------------------------------------------------------------------
-#include "swmi_cells_gen.inc"   // CellsAsm<R, ACGT, STRICT>: hand-scheduled instruction stream
+#include "swmi_cells_gen.inc"   // CellsAsm<R, ACGT, STRICT, DIRS>: hand-scheduled instruction stream
 
 // Plain C++ statement of the same update (build with -DSWMI_NO_ASM to A/B against the asm stream).
-template <int R, bool ACGT, bool STRICT>
+template <int R, bool ACGT, bool STRICT, bool DIRS>
 struct CellsRef {
     static __device__ __forceinline__ void step(const int (&hin)[R], int (&hout)[R], uint32_t (&acc)[R], const int (&q)[R],
                                                 int rb, int diag, int up, int gap, int vmat, int vmis) {
@@ -86,9 +95,11 @@ struct CellsRef {
             const int t2 = (up > left ? up : left) + gap;   // :227, :235 (InsDelScore :277-280)
             int hv = a > t2 ? a : t2;
             hv = hv > 0 ? hv : 0;                           // `int max = 0` :223
-            const bool bi = STRICT ? (up > left) : (up >= left);
-            const bool ba = STRICT ? (a > t2) : (a >= t2);
-            acc[k] = (acc[k] << 2) | (bi ? 2u : 0u) | (ba ? 1u : 0u);
+            if (DIRS) {
+                const bool bi = STRICT ? (up > left) : (up >= left);
+                const bool ba = STRICT ? (a > t2) : (a >= t2);
+                acc[k] = (acc[k] << 2) | (bi ? 2u : 0u) | (ba ? 1u : 0u);
+            }
             diag = left;
             up = hv;
             hout[k] = hv;
@@ -97,14 +108,22 @@ struct CellsRef {
 };
 
 #ifdef SWMI_NO_ASM
-template <int R, bool ACGT, bool STRICT> using Cells = CellsRef<R, ACGT, STRICT>;
+template <int R, bool ACGT, bool STRICT, bool DIRS> using Cells = CellsRef<R, ACGT, STRICT, DIRS>;
 #else
-template <int R, bool ACGT, bool STRICT> using Cells = CellsAsm<R, ACGT, STRICT>;
+template <int R, bool ACGT, bool STRICT, bool DIRS> using Cells = CellsAsm<R, ACGT, STRICT, DIRS>;
 #endif
 
+// What a 16-step block does besides the scores:
+//   SWMI_MODE_FIELD   fill, direction bits packed and stored to HBM, tied maxima tracked          (mode 0 fill kernel)
+//   SWMI_MODE_SCORE   fill, scores only (5 VALU per cell) + lane-state checkpoints, maxima tracked (mode 1 fill kernel)
+//   SWMI_MODE_REPLAY  a 64-step window re-swept from a checkpoint, direction bits to LDS, nothing tracked (mode 1 traceback)
+#define SWMI_MODE_FIELD  0
+#define SWMI_MODE_SCORE  1
+#define SWMI_MODE_REPLAY 2
+
 // ------------------------------------------------------------------------------------------------
-// rare path: at step t some lane reached the running maximum.  Out of line so the 16x unrolled hot
-// block stays small.  thr / cnt are wave-uniform; they travel packed in one 64-bit value.
+// rare path: at step t some lane reached the running maximum.  thr / cnt are wave-uniform; they travel
+// packed in one 64-bit value.
 // ------------------------------------------------------------------------------------------------
 template <int R>
 __device__ __forceinline__ unsigned long long
@@ -120,18 +139,18 @@ record_max_cells(int h0, int h1, int h2, int h3, uint32_t t, uint32_t lane_eff, 
         v[k] = (active && row0 + k < m) ? hh[k] : -1;   // rows past the read and lanes off their range never count
         cand = cand > v[k] ? cand : v[k];
     }
-    if (__ballot(cand >= thr) == 0) return ((unsigned long long)(uint32_t)thr << 32) | cnt;   // stale trigger
+    if (BALLOT(cand >= thr) == 0) return ((unsigned long long)(uint32_t)thr << 32) | cnt;   // stale trigger
     // strict increase: climb to the wave's maximum by lane hops (no reduction network needed: few lanes exceed)
-    uint64_t gt = __ballot(cand > thr);
+    uint64_t gt = BALLOT(cand > thr);
     while (gt) {                                        // SmithWaterman.java:176-181
         thr = __builtin_amdgcn_readlane(cand, (int)__builtin_ctzll(gt));
         cnt = 0;
-        gt = __ballot(cand > thr);
+        gt = BALLOT(cand > thr);
     }
 #pragma unroll
     for (int k = 0; k < R; ++k) {
         const bool hit = v[k] == thr;                   // :182-185
-        const uint64_t hm = __ballot(hit);
+        const uint64_t hm = BALLOT(hit);
         if (hm) {
             const uint32_t pos = cnt + lanemask_lt_count(hm);
             if (hit && pos < ccap) cells[pos] = make_uint2(row0 + k + 1, c0 + 1u);
@@ -142,16 +161,14 @@ record_max_cells(int h0, int h1, int h2, int h3, uint32_t t, uint32_t lane_eff, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// fill: one pair, one wavefront.  R rows per lane; ACGT = both sequences pure ACGT and scores fit a
-// signed byte (profile lookup by v_bfe_i32 instead of compare+select); STRICT = DistributedSW tie order;
-// MULTI = more than one strip of 64*R rows (seam row through memory).
+// sweep state of one wavefront
 // ------------------------------------------------------------------------------------------------
 template <int R>
 struct FillState {
-    int h[R];            // H of the lane's rows after the latest even-numbered... see fill_block16: ping
-    int g[R];            // pong
-    uint32_t acc[R];
-    int q[R];
+    int h[R];            // H of the lane's rows: read by even steps of a block, written by odd ones
+    int g[R];            // ... and the other way round (ping-pong, see fill_block16)
+    uint32_t acc[R];     // direction bits of the last <= 16 steps
+    int q[R];            // ACGT: the row's 4 x int8 score profile; else the read's base code
     int nprev, rb;
     int thr;             // wave-uniform running maximum
     uint32_t cnt;        // wave-uniform number of cells equal to thr
@@ -159,6 +176,31 @@ struct FillState {
     uint32_t events;     // slow-path entries (diagnostics only)
     bool dbg_skip;       // diagnostics only
 };
+
+// read-side operands of this lane's rows, and a zero H column
+template <int R, bool ACGT>
+__device__ __forceinline__ void setup_rows(FillState<R> &S, const uint32_t *__restrict__ readw, uint32_t row0, uint32_t m,
+                                           int match, int mismatch) {
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const uint32_t row = row0 + k;
+        if (ACGT) {                                   // 4 signed score bytes indexed by the reference code
+            uint32_t p = (uint32_t)(mismatch & 0xFF) * 0x01010101u;
+            if (row < m) {
+                const uint32_t c = seq_code(readw, row);      // 0, 8, 16 or 24
+                p = (p & ~(0xFFu << c)) | ((uint32_t)(match & 0xFF) << c);
+            }
+            S.q[k] = (int)p;
+        } else {
+            S.q[k] = row < m ? (int)seq_code(readw, row) : (int)SWMI_CODE_PAD;
+        }
+        S.h[k] = 0;
+        S.g[k] = 0;
+        S.acc[k] = 0;
+    }
+    S.nprev = 0;                                     // N received one step earlier = NW of this step
+    S.rb = 0;                                        // reference base operand of this lane's current column
+}
 
 template <int R>
 __device__ __forceinline__ void handle_pending(FillState<R> &S, const int (&hv)[R], uint32_t t, uint32_t lane_eff,
@@ -183,7 +225,7 @@ __device__ __forceinline__ void handle_pending(FillState<R> &S, const int (&hv)[
 // the values of step t-1 are still there.  That lets the tied-maximum test of step t-1 -- a compare into
 // an SGPR pair -- be branched on one step later, when its result has long arrived, instead of stalling the
 // wave on a VALU->scalar-branch dependency every step (measured: 57 of 197 cycles per step).
-template <int R, bool ACGT, bool STRICT, bool MULTI, bool PRED>
+template <int R, bool ACGT, bool STRICT, bool MULTI, bool PRED, int MODE>
 __device__ __forceinline__ void fill_block16(FillState<R> &S, const uint4 w, const uint32_t t0,
                                              const uint32_t lane, const uint32_t lane_eff,
                                              const uint32_t n, const uint32_t m, const uint32_t row0,
@@ -191,6 +233,9 @@ __device__ __forceinline__ void fill_block16(FillState<R> &S, const uint4 w, con
                                              const int seamv, const bool reads_seam, const bool feeds_seam,
                                              int32_t *__restrict__ seam_out,
                                              uint2 *__restrict__ cells, const uint32_t ccap) {
+    constexpr bool DIRS = MODE != SWMI_MODE_SCORE;
+    constexpr bool TRACK = MODE != SWMI_MODE_REPLAY;
+    using C = Cells<R, ACGT, DIRS ? STRICT : false, DIRS>;
 #pragma unroll
     for (uint32_t s = 0; s < 16; ++s) {
         const int (&hin)[R] = (s & 1u) ? S.g : S.h;
@@ -206,36 +251,62 @@ __device__ __forceinline__ void fill_block16(FillState<R> &S, const uint4 w, con
         } else {
             nin = wave_shr1_zero(hin[R - 1]);
         }
-        int mrow;
+        int mrow = -1;
         if (PRED) {
             const uint32_t c0 = t0 + s - lane_eff;                         // column index j-1 of this lane
-            mrow = -1;
             if (c0 < n) {
-                Cells<R, ACGT, STRICT>::step(hin, hout, S.acc, S.q, S.rb, S.nprev, nin, gap, vmat, vmis);
-                mrow = hout[0];
+                C::step(hin, hout, S.acc, S.q, S.rb, S.nprev, nin, gap, vmat, vmis);
+                if (TRACK) {
+                    mrow = hout[0];
 #pragma unroll
-                for (int k = 1; k < R; ++k) mrow = mrow > hout[k] ? mrow : hout[k];
-                if (MULTI && feeds_seam && lane == WAVE - 1) seam_out[c0 + 1] = hout[R - 1];
+                    for (int k = 1; k < R; ++k) mrow = mrow > hout[k] ? mrow : hout[k];
+                }
+                if (MULTI && TRACK && feeds_seam && lane == WAVE - 1) seam_out[c0 + 1] = hout[R - 1];
             } else {
 #pragma unroll
                 for (int k = 0; k < R; ++k) hout[k] = hin[k];             // a lane off its range keeps its state
             }
         } else {
-            Cells<R, ACGT, STRICT>::step(hin, hout, S.acc, S.q, S.rb, S.nprev, nin, gap, vmat, vmis);
-            mrow = hout[0];
+            C::step(hin, hout, S.acc, S.q, S.rb, S.nprev, nin, gap, vmat, vmis);
+            if (TRACK) {
+                mrow = hout[0];
 #pragma unroll
-            for (int k = 1; k < R; ++k) mrow = mrow > hout[k] ? mrow : hout[k];
-            if (MULTI && feeds_seam && lane == WAVE - 1) seam_out[t0 + s - lane + 1] = hout[R - 1];
+                for (int k = 1; k < R; ++k) mrow = mrow > hout[k] ? mrow : hout[k];
+            }
+            if (MULTI && TRACK && feeds_seam && lane == WAVE - 1) seam_out[t0 + s - lane + 1] = hout[R - 1];
         }
         S.nprev = nin;
-        const uint64_t ev = __ballot(mrow >= S.thr);      // all 64 lanes vote: thr / cnt stay wave-uniform
-        if (__builtin_expect(S.ev_prev != 0, 0))                           // step t0+s-1, values still in hin
-            handle_pending<R>(S, hin, t0 + s - 1u, lane_eff, n, row0, m, cells, ccap);
-        S.ev_prev = ev;
+        if (TRACK) {
+            const uint64_t ev = BALLOT(mrow >= S.thr);      // all 64 lanes vote: thr / cnt stay wave-uniform
+            if (__builtin_expect(S.ev_prev != 0, 0))                           // step t0+s-1, values still in hin
+                handle_pending<R>(S, hin, t0 + s - 1u, lane_eff, n, row0, m, cells, ccap);
+            S.ev_prev = ev;
+        }
     }
 }
 
-template <int R, bool ACGT, bool STRICT, bool MULTI>
+// geometry shared by the sweep and its replay
+struct StripGeom {
+    uint32_t rps, n_strips, wblocks, n_ck;
+    uint64_t strip_words;        // dwords of workspace per strip (direction field or checkpoints)
+};
+template <int R>
+__device__ __forceinline__ StripGeom strip_geom(uint32_t m, uint32_t n, uint32_t mode) {
+    StripGeom g;
+    g.rps = WAVE * R;
+    g.n_strips = (m + g.rps - 1) / g.rps;
+    g.wblocks = (n + 63u + 15u) / 16u;                       // 16-step blocks reserved per strip
+    g.n_ck = (g.wblocks + SWMI_CK_BLOCKS - 1u) / SWMI_CK_BLOCKS;
+    g.strip_words = mode == 0 ? (uint64_t)g.wblocks * R * WAVE : (uint64_t)g.n_ck * (R + 2) * WAVE;
+    return g;
+}
+
+// ------------------------------------------------------------------------------------------------
+// fill: one pair, one wavefront.  R rows per lane; ACGT = both sequences pure ACGT and scores fit a
+// signed byte (profile lookup by v_bfe_i32 instead of compare+select); STRICT = DistributedSW tie order;
+// MULTI = more than one strip of 64*R rows (seam rows through memory); MODE = FIELD or SCORE.
+// ------------------------------------------------------------------------------------------------
+template <int R, bool ACGT, bool STRICT, bool MULTI, int MODE>
 __device__ __forceinline__ void fill_pair(const FillArgs &A, const PairDesc pd, const uint32_t lane) {
     const SeqDesc rd = A.refs[pd.ref_id];
     const SeqDesc qd = A.reads[pd.read_id];
@@ -243,11 +314,7 @@ __device__ __forceinline__ void fill_pair(const FillArgs &A, const PairDesc pd, 
     const uint32_t *__restrict__ refw = A.seqw + rd.boff;
     const uint32_t *__restrict__ readw = A.seqw + qd.boff;
     const int match = A.match, mismatch = A.mismatch, gap = A.gap;
-
-    const uint32_t rps = WAVE * R;                       // rows per strip
-    const uint32_t n_strips = (m + rps - 1) / rps;
-    const uint32_t wblocks = (n + 63u + 15u) / 16u;      // 16-step blocks reserved per strip
-    const uint64_t strip_words = (uint64_t)wblocks * R * WAVE;
+    const StripGeom G = strip_geom<R>(m, n, MODE == SWMI_MODE_FIELD ? 0u : 1u);
 
     const uint64_t cbase = A.cells_off ? A.cells_off[pd.out_id] : (uint64_t)pd.out_id * A.cell_cap;
     const uint32_t ccap = A.cells_cap ? A.cells_cap[pd.out_id] : A.cell_cap;
@@ -261,43 +328,23 @@ __device__ __forceinline__ void fill_pair(const FillArgs &A, const PairDesc pd, 
     S.dbg_skip = A.dbg && (A.dbg_pad != 0);
     const unsigned long long t_start = A.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
 
-    for (uint32_t s = 0; s < n_strips; ++s) {
-        const uint32_t row0 = s * rps + lane * R;        // 0-based first row of this lane
-        const uint32_t rows_left = m - s * rps;
-        const uint32_t lact = rows_left >= rps ? WAVE : (rows_left + R - 1) / R;   // lanes holding rows
+    for (uint32_t s = 0; s < G.n_strips; ++s) {
+        const uint32_t row0 = s * G.rps + lane * R;        // 0-based first row of this lane
+        const uint32_t rows_left = m - s * G.rps;
+        const uint32_t lact = rows_left >= G.rps ? WAVE : (rows_left + R - 1) / R;   // lanes holding rows
         const uint32_t T = n + lact - 1;                 // steps of this strip
         const uint32_t lane_eff = lane < lact ? lane : 0x40000000u;   // lanes without rows are never in range
+        setup_rows<R, ACGT>(S, readw, row0, m, match, mismatch);
 
-        // read-side operands of this lane's rows
-#pragma unroll
-        for (int k = 0; k < R; ++k) {
-            const uint32_t row = row0 + k;
-            if (ACGT) {                                   // 4 signed score bytes indexed by the reference code
-                uint32_t p = (uint32_t)(mismatch & 0xFF) * 0x01010101u;
-                if (row < m) {
-                    const uint32_t c = seq_code(readw, row);      // 0, 8, 16 or 24
-                    p = (p & ~(0xFFu << c)) | ((uint32_t)(match & 0xFF) << c);
-                }
-                S.q[k] = (int)p;
-            } else {
-                S.q[k] = row < m ? (int)seq_code(readw, row) : (int)SWMI_CODE_PAD;
-            }
-            S.h[k] = 0;
-            S.g[k] = 0;
-            S.acc[k] = 0;
-        }
-        S.nprev = 0;                                     // N received one step earlier = NW of this step
-        S.rb = 0;                                        // reference base operand of this lane's current column
-
-        uint32_t *__restrict__ dirp = A.dir + pd.dir_off + s * strip_words + lane;
+        uint32_t *__restrict__ wsp = A.dir + pd.dir_off + s * G.strip_words + lane;   // this strip's workspace
         const int32_t *seam_in = nullptr;
         int32_t *seam_out = nullptr;
         if (MULTI) {
-            int32_t *sb = A.seam + pd.seam_off;
-            seam_in = sb + ((s + 1) & 1) * (uint64_t)(n + 1);    // written by strip s-1
-            seam_out = sb + (s & 1) * (uint64_t)(n + 1);
+            int32_t *sb = A.seam + pd.seam_off;                       // row s = H of the strip's last read row
+            seam_in = sb + (uint64_t)(s > 0 ? s - 1 : 0) * (n + 1);
+            seam_out = sb + (uint64_t)s * (n + 1);
         }
-        const bool feeds_seam = MULTI && (s + 1 < n_strips);
+        const bool feeds_seam = MULTI && (s + 1 < G.n_strips);
         const bool reads_seam = MULTI && (s > 0);
 
         const uint32_t nblk = (T + 15u) / 16u;
@@ -307,6 +354,14 @@ __device__ __forceinline__ void fill_pair(const FillArgs &A, const PairDesc pd, 
             const uint4 w = wnext;                       // base codes of columns 16tb+1 .. 16tb+16
             wnext = refq[tb + 1];                        // prefetch (images are padded)
             const uint32_t t0 = 16u * tb;
+            if (MODE == SWMI_MODE_SCORE && (tb % SWMI_CK_BLOCKS) == 0u) {
+                // checkpoint: everything a replay of steps t0.. needs from this lane ([ck][slot][lane], 256 B stores)
+                uint32_t *__restrict__ ck = wsp + (uint64_t)(tb / SWMI_CK_BLOCKS) * (R + 2) * WAVE;
+#pragma unroll
+                for (int k = 0; k < R; ++k) ck[k * WAVE] = (uint32_t)S.h[k];
+                ck[R * WAVE] = (uint32_t)S.nprev;
+                ck[(R + 1) * WAVE] = (uint32_t)S.rb;
+            }
             int seamv = 0;
             if (reads_seam) {
                 // seam_in[16tb + 1 + lane] for lanes 0..15: N of lane 0 for the 16 steps of this block
@@ -315,20 +370,22 @@ __device__ __forceinline__ void fill_pair(const FillArgs &A, const PairDesc pd, 
             }
             const bool steady = (t0 + 1u >= lact) && (t0 + 15u < n);
             if (steady)
-                fill_block16<R, ACGT, STRICT, MULTI, false>(S, w, t0, lane, lane_eff, n, m, row0, gap, match, mismatch,
-                                                            seamv, reads_seam, feeds_seam, seam_out, cells, ccap);
+                fill_block16<R, ACGT, STRICT, MULTI, false, MODE>(S, w, t0, lane, lane_eff, n, m, row0, gap, match, mismatch,
+                                                                  seamv, reads_seam, feeds_seam, seam_out, cells, ccap);
             else
-                fill_block16<R, ACGT, STRICT, MULTI, true>(S, w, t0, lane, lane_eff, n, m, row0, gap, match, mismatch,
-                                                           seamv, reads_seam, feeds_seam, seam_out, cells, ccap);
+                fill_block16<R, ACGT, STRICT, MULTI, true, MODE>(S, w, t0, lane, lane_eff, n, m, row0, gap, match, mismatch,
+                                                                 seamv, reads_seam, feeds_seam, seam_out, cells, ccap);
 
-            // ---- end of a 16-step block: one coalesced 256 B store per row slot -------------------
-            // lanes that finished their last column inside this block still owe the missing shifts
-            const int miss = (int)(t0 + 15u) - ((int)(lane + n) - 1);
+            if (MODE == SWMI_MODE_FIELD) {
+                // ---- end of a 16-step block: one coalesced 256 B store per row slot -------------------
+                // lanes that finished their last column inside this block still owe the missing shifts
+                const int miss = (int)(t0 + 15u) - ((int)(lane + n) - 1);
 #pragma unroll
-            for (int k = 0; k < R; ++k) {
-                uint32_t v = S.acc[k];
-                if (miss > 0 && miss < 16) v <<= 2 * miss;
-                dirp[((uint64_t)tb * R + k) * WAVE] = v;
+                for (int k = 0; k < R; ++k) {
+                    uint32_t v = S.acc[k];
+                    if (miss > 0 && miss < 16) v <<= 2 * miss;
+                    wsp[((uint64_t)tb * R + k) * WAVE] = v;
+                }
             }
         }
         // the tied-maximum test of the strip's last step is still pending (16 steps per block: its H is in S.h)
@@ -351,50 +408,60 @@ __device__ __forceinline__ void fill_pair(const FillArgs &A, const PairDesc pd, 
     }
 }
 
-template <bool ACGT, bool STRICT>
+template <bool ACGT, bool STRICT, int MODE>
 __device__ __forceinline__ void fill_dispatch(const FillArgs &A, const PairDesc pd, uint32_t lane, uint32_t m) {
     const uint32_t R = swmi_rows_per_lane(m);
-    if (R == 1)      fill_pair<1, ACGT, STRICT, false>(A, pd, lane);
-    else if (R == 2) fill_pair<2, ACGT, STRICT, false>(A, pd, lane);
-    else if (R == 3) fill_pair<3, ACGT, STRICT, false>(A, pd, lane);
-    else if (m <= WAVE * SWMI_RMAX) fill_pair<SWMI_RMAX, ACGT, STRICT, false>(A, pd, lane);
-    else             fill_pair<SWMI_RMAX, ACGT, STRICT, true>(A, pd, lane);
+    if (R == 1)      fill_pair<1, ACGT, STRICT, false, MODE>(A, pd, lane);
+    else if (R == 2) fill_pair<2, ACGT, STRICT, false, MODE>(A, pd, lane);
+    else if (R == 3) fill_pair<3, ACGT, STRICT, false, MODE>(A, pd, lane);
+    else if (m <= WAVE * SWMI_RMAX) fill_pair<SWMI_RMAX, ACGT, STRICT, false, MODE>(A, pd, lane);
+    else             fill_pair<SWMI_RMAX, ACGT, STRICT, true, MODE>(A, pd, lane);
 }
 
 // 4 wavefronts per workgroup, one pair each: the 4 waves of a workgroup land on the 4 SIMDs of a CU, so a
-// grid of n_pairs/4 workgroups spreads evenly over the SIMDs (single-wave workgroups were observed to pile
-// up on some SIMDs, and this instruction mix saturates a SIMD with little more than one wave).
+// grid of n_pairs/4 workgroups spreads evenly over the SIMDs.
 #define FILL_WAVES 4
-extern "C" __global__ void __launch_bounds__(WAVE * FILL_WAVES)
-sw_fill_kernel(const FillArgs A) {
+template <int MODE>
+__device__ __forceinline__ void fill_entry(const FillArgs &A) {
     const uint32_t pair = blockIdx.x * FILL_WAVES + (threadIdx.x >> 6);
     if (pair >= A.n_pairs) return;
     const uint32_t lane = threadIdx.x & 63u;
-    if (pair == 0 && lane == 0 && A.hdr) { A.hdr->used_words = 0; A.hdr->n_records = 0; }   // arena reset for the traceback kernel
+    if (pair == 0 && lane == 0 && A.hdr) { A.hdr->used_words = 0; A.hdr->n_records = 0; }   // arena reset for the traceback kernel that follows
     const PairDesc pd = A.pairs[pair];
     const SeqDesc rd = A.refs[pd.ref_id];
     const SeqDesc qd = A.reads[pd.read_id];
     // profile lookup needs both sequences pure ACGT and scores that fit a signed byte
     const bool acgt = rd.acgt && qd.acgt &&
                       A.match >= -128 && A.match <= 127 && A.mismatch >= -128 && A.mismatch <= 127;
-    if (acgt) {
-        if (A.strict) fill_dispatch<true, true>(A, pd, lane, qd.len);
-        else          fill_dispatch<true, false>(A, pd, lane, qd.len);
+    if (MODE == SWMI_MODE_SCORE) {                     // scores do not depend on the tie order
+        if (acgt) fill_dispatch<true, false, MODE>(A, pd, lane, qd.len);
+        else      fill_dispatch<false, false, MODE>(A, pd, lane, qd.len);
+    } else if (acgt) {
+        if (A.strict) fill_dispatch<true, true, MODE>(A, pd, lane, qd.len);
+        else          fill_dispatch<true, false, MODE>(A, pd, lane, qd.len);
     } else {
-        if (A.strict) fill_dispatch<false, true>(A, pd, lane, qd.len);
-        else          fill_dispatch<false, false>(A, pd, lane, qd.len);
+        if (A.strict) fill_dispatch<false, true, MODE>(A, pd, lane, qd.len);
+        else          fill_dispatch<false, false, MODE>(A, pd, lane, qd.len);
     }
 }
+
+extern "C" __global__ void __launch_bounds__(WAVE * FILL_WAVES)
+sw_fill_kernel(const FillArgs A) { fill_entry<SWMI_MODE_FIELD>(A); }
+
+extern "C" __global__ void __launch_bounds__(WAVE * FILL_WAVES)
+sw_fill_score_kernel(const FillArgs A) { fill_entry<SWMI_MODE_SCORE>(A); }
 
 // ------------------------------------------------------------------------------------------------
 // traceback: SWMI_TB_SLOTS wavefronts per pair (slot x walks the tied cells x, x+SLOTS, ...).
 //
 // The walk is a chain of dependent 2-bit lookups; straight from HBM that is ~1 us per step, and even from
 // LDS a one-cell-at-a-time scalar walk costs ~100 instruction issues per step.  So:
-//  * the wave copies a TILE of the direction field -- SWMI_TB_BLOCKS 16-step blocks x all 64*R row slots
-//    of the strip, i.e. every cell whose anti-diagonal step lies in a 256-step window -- into LDS with
-//    coalesced 256 B loads (all in flight at once), plus the matching window of reference codes and the
-//    whole read;
+//  * the wave brings a TILE of the direction field -- every cell whose anti-diagonal step lies in a window
+//    of 16-step blocks, all 64*R row slots of the strip -- into LDS, plus the matching window of reference
+//    codes and the whole read.  Mode 0 copies it from the HBM direction field (16 blocks, coalesced 256 B
+//    loads, all in flight at once); mode 1 RE-SWEEPS 4 blocks (64 steps) from the lane-state checkpoint the
+//    score-only fill left behind, this time with the direction bits (the same instruction stream as the
+//    mode-0 fill), which is cheaper than having every pair pay 4 more VALU per cell in the fill;
 //  * it then advances by RUNS: lane x looks at the cell x steps up the current diagonal, a ballot gives the
 //    length of the run of "alignment" moves, a second ballot over per-lane prefix scores finds where the
 //    tracked score H(pred) = H - s(ref,read) would reach 0 (`while (score > 0)`, SmithWaterman.java:380), and
@@ -404,24 +471,94 @@ sw_fill_kernel(const FillArgs A) {
 #define SWMI_TB_REFWIN_WORDS 96u      // (16*16 + 63) / 4 + slack
 #define SWMI_TB_SLOTS 4u
 
-template <uint32_t R>
+// mode 1: re-sweep the window of SWMI_CK_BLOCKS blocks that starts at block `wlo` of strip `s` into lds_tile
+template <int R, bool ACGT, bool STRICT, bool MULTI>
+__device__ __forceinline__ void replay_window(const TraceArgs &A, const PairDesc pd, const uint32_t n, const uint32_t m,
+                                              const uint32_t *__restrict__ refw, const uint32_t *__restrict__ readw,
+                                              const StripGeom G, const uint32_t s, const uint32_t wlo,
+                                              const uint32_t lane, uint32_t *__restrict__ lds_tile) {
+    FillState<R> S;
+    S.thr = 0x7FFFFFFF; S.cnt = 0; S.ev_prev = 0; S.events = 0; S.dbg_skip = false;
+    const uint32_t row0 = s * G.rps + lane * R;
+    const uint32_t rows_left = m - s * G.rps;
+    const uint32_t lact = rows_left >= G.rps ? WAVE : (rows_left + R - 1) / R;
+    const uint32_t T = n + lact - 1;
+    const uint32_t lane_eff = lane < lact ? lane : 0x40000000u;
+    setup_rows<R, ACGT>(S, readw, row0, m, A.match, A.mismatch);
+    const uint32_t *__restrict__ ck = A.dir + pd.dir_off + s * G.strip_words +
+                                      (uint64_t)(wlo / SWMI_CK_BLOCKS) * (R + 2) * WAVE + lane;
+#pragma unroll
+    for (int k = 0; k < R; ++k) S.h[k] = (int)ld_l2(ck + k * WAVE);
+    S.nprev = (int)ld_l2(ck + R * WAVE);
+    S.rb = (int)ld_l2(ck + (R + 1) * WAVE);
+    const int32_t *seam_in = nullptr;
+    if (MULTI) seam_in = A.seam + pd.seam_off + (uint64_t)(s > 0 ? s - 1 : 0) * (n + 1);
+    const bool reads_seam = MULTI && (s > 0);
+    const uint32_t nblk = (T + 15u) / 16u;
+    const uint4 *__restrict__ refq = reinterpret_cast<const uint4 *>(refw);
+    uint4 wv[SWMI_CK_BLOCKS];                                  // the window's base codes: all loads in flight at once
+#pragma unroll
+    for (uint32_t b = 0; b < SWMI_CK_BLOCKS; ++b) wv[b] = refq[wlo + b];     // images are padded past nblk
+#pragma unroll
+    for (uint32_t b = 0; b < SWMI_CK_BLOCKS; ++b) {
+        const uint32_t tb = wlo + b;
+        if (tb >= nblk) break;
+        const uint4 w = wv[b];
+        const uint32_t t0 = 16u * tb;
+        int seamv = 0;
+        if (reads_seam) {
+            const uint32_t col = t0 + 1u + (lane & 15u);
+            seamv = col <= n ? (int)ld_l2((const uint32_t *)seam_in + col) : 0;
+        }
+        const bool steady = (t0 + 1u >= lact) && (t0 + 15u < n);
+        if (steady)
+            fill_block16<R, ACGT, STRICT, MULTI, false, SWMI_MODE_REPLAY>(S, w, t0, lane, lane_eff, n, m, row0, A.gap, A.match, A.mismatch,
+                                                                          seamv, reads_seam, false, nullptr, nullptr, 0u);
+        else
+            fill_block16<R, ACGT, STRICT, MULTI, true, SWMI_MODE_REPLAY>(S, w, t0, lane, lane_eff, n, m, row0, A.gap, A.match, A.mismatch,
+                                                                         seamv, reads_seam, false, nullptr, nullptr, 0u);
+        const int miss = (int)(t0 + 15u) - ((int)(lane + n) - 1);
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            uint32_t v = S.acc[k];
+            if (miss > 0 && miss < 16) v <<= 2 * miss;
+            lds_tile[(b * R + k) * WAVE + lane] = v;
+        }
+    }
+}
+
+template <int R, bool MULTI>
+__device__ __forceinline__ void replay_dispatch(const TraceArgs &A, const PairDesc pd, uint32_t n, uint32_t m, bool acgt,
+                                                const uint32_t *__restrict__ refw, const uint32_t *__restrict__ readw,
+                                                const StripGeom G, uint32_t s, uint32_t wlo, uint32_t lane, uint32_t *lds_tile) {
+    if (acgt) {
+        if (A.strict) replay_window<R, true, true, MULTI>(A, pd, n, m, refw, readw, G, s, wlo, lane, lds_tile);
+        else          replay_window<R, true, false, MULTI>(A, pd, n, m, refw, readw, G, s, wlo, lane, lds_tile);
+    } else {
+        if (A.strict) replay_window<R, false, true, MULTI>(A, pd, n, m, refw, readw, G, s, wlo, lane, lds_tile);
+        else          replay_window<R, false, false, MULTI>(A, pd, n, m, refw, readw, G, s, wlo, lane, lds_tile);
+    }
+}
+
+template <int R, int TMODE>
 __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDesc pd, const PairOut po,
-                                               const uint32_t lane, const uint32_t slot, uint32_t *__restrict__ lds) {
+                                               const uint32_t lane, const uint32_t slot, const uint32_t nslots,
+                                               uint32_t *__restrict__ lds) {
     const SeqDesc rd = A.refs[pd.ref_id];
     const SeqDesc qd = A.reads[pd.read_id];
     const uint32_t n = rd.len, m = qd.len;
     const uint32_t *__restrict__ refw = A.seqw + rd.boff;
     const uint32_t *__restrict__ readw = A.seqw + qd.boff;
-    const uint32_t rps = WAVE * R;
-    const uint32_t wblocks = (n + 63u + 15u) / 16u;
-    const uint64_t strip_words = (uint64_t)wblocks * R * WAVE;
+    const StripGeom G = strip_geom<R>(m, n, TMODE);
+    const uint32_t rps = G.rps;
     const uint32_t *__restrict__ dirp = A.dir + pd.dir_off;
     const uint32_t umat = (uint32_t)A.match, umis = (uint32_t)A.mismatch, ugap = (uint32_t)A.gap;
+    const bool acgt = rd.acgt && qd.acgt && A.match >= -128 && A.match <= 127 && A.mismatch >= -128 && A.mismatch <= 127;
 
     uint32_t *lds_ops = lds;                                   // [A.lds_words]      one op per BYTE, staged per alignment
     uint32_t *lds_read = lds_ops + A.lds_words;                // [A.lds_read_words] the read's codes
     uint32_t *lds_ref = lds_read + A.lds_read_words;           // [SWMI_TB_REFWIN_WORDS]
-    uint32_t *lds_tile = lds_ref + SWMI_TB_REFWIN_WORDS;       // [SWMI_TB_BLOCKS * R * 64]
+    uint32_t *lds_tile = lds_ref + SWMI_TB_REFWIN_WORDS;       // [WIN * R * 64]
     uint8_t *ops_b = reinterpret_cast<uint8_t *>(lds_ops);
     const uint8_t *read_b = reinterpret_cast<const uint8_t *>(lds_read);
     const uint8_t *ref_b = reinterpret_cast<const uint8_t *>(lds_ref);
@@ -439,20 +576,20 @@ __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDes
     for (uint32_t base = 0; base < ncell; base += WAVE) {
         const uint32_t idx = base + lane;
         uint2 mine = make_uint2(0, 0);
-        if (idx < ncell) mine = cells[idx];
+        if (idx < ncell) { mine.x = ld_l2(&cells[idx].x); mine.y = ld_l2(&cells[idx].y); }
         const uint64_t mykey = A.strict ? (((uint64_t)(mine.x + mine.y) << 32) | mine.y)
                                         : (((uint64_t)mine.x << 32) | mine.y);
         uint32_t rank = 0;
         if (ncell > 1) {
             for (uint32_t o = 0; o < ncell; ++o) {
-                const uint2 c = cells[o];
+                uint2 c; c.x = ld_l2(&cells[o].x); c.y = ld_l2(&cells[o].y);
                 const uint64_t kk = A.strict ? (((uint64_t)(c.x + c.y) << 32) | c.y) : (((uint64_t)c.x << 32) | c.y);
                 rank += (kk < mykey) ? 1u : 0u;
             }
         }
         const uint32_t nhere = ncell - base < WAVE ? ncell - base : WAVE;
 
-        for (uint32_t a = slot; a < nhere; a += SWMI_TB_SLOTS) {
+        for (uint32_t a = slot; a < nhere; a += nslots) {
             const uint32_t ci = __builtin_amdgcn_readlane((int)mine.x, a);
             const uint32_t cj = __builtin_amdgcn_readlane((int)mine.y, a);
             const uint32_t crank = __builtin_amdgcn_readlane((int)rank, a);
@@ -463,76 +600,118 @@ __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDes
             uint32_t n_ops = 0;
             int begin = 0;
             while ((int)score > 0) {
-                // ---- stage the tile that ends at the current cell's step ----
+                // ---- stage the window that holds the current cell's step ----
                 const uint32_t s = (i - 1u) / rps;
                 int rho = (int)((i - 1u) - s * rps);                               // row slot within the strip
                 const uint32_t t_cur = j - 1u + (uint32_t)rho / R;
                 const uint32_t whi = t_cur >> 4;
-                const uint32_t wlo = whi >= SWMI_TB_BLOCKS - 1u ? whi - (SWMI_TB_BLOCKS - 1u) : 0u;
-                const uint32_t nb = whi - wlo + 1u;
-                const uint32_t *__restrict__ src = dirp + s * strip_words + (uint64_t)wlo * R * WAVE + lane;
-                __syncthreads();
-                for (uint32_t x = 0; x < nb * R; ++x) lds_tile[x * WAVE + lane] = src[(uint64_t)x * WAVE];
+                uint32_t wlo, nb;
+                if (TMODE == 0) {
+                    wlo = whi >= SWMI_TB_BLOCKS - 1u ? whi - (SWMI_TB_BLOCKS - 1u) : 0u;
+                    nb = whi - wlo + 1u;
+                } else {
+                    wlo = whi - whi % SWMI_CK_BLOCKS;                              // windows start at checkpoints
+                    nb = SWMI_CK_BLOCKS;
+                }
+                WAVE_SYNC();
+                if (TMODE == 0) {
+                    const uint32_t *__restrict__ src = dirp + s * G.strip_words + (uint64_t)wlo * R * WAVE + lane;
+                    for (uint32_t x = 0; x < nb * R; ++x) lds_tile[x * WAVE + lane] = src[(uint64_t)x * WAVE];
+                } else {
+                    bool multi = false;
+                    if constexpr (R == SWMI_RMAX) multi = m > WAVE * SWMI_RMAX;
+                    if constexpr (R == SWMI_RMAX) {
+                        if (multi) replay_dispatch<R, true>(A, pd, n, m, acgt, refw, readw, G, s, wlo, lane, lds_tile);
+                    }
+                    if (!multi) replay_dispatch<R, false>(A, pd, n, m, acgt, refw, readw, G, s, wlo, lane, lds_tile);
+                }
                 const int clo = (int)(16u * wlo) - 63;
                 const uint32_t cw0 = clo > 0 ? (uint32_t)clo >> 2 : 0u;           // first dword of the reference window
-                const uint32_t cw1 = (16u * whi + 15u) >> 2;
+                const uint32_t cw1 = (16u * (wlo + nb) - 1u) >> 2;
                 for (uint32_t x = cw0 + lane; x <= cw1 && x < (n + 3u) / 4u; x += WAVE) lds_ref[x - cw0] = refw[x];
-                __syncthreads();
+                WAVE_SYNC();
                 const int tmin = (int)(16u * wlo);
-
                 const unsigned long long tw0 = A.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
 
+                // Three diagonals are inspected at once, 21 lanes each: group 0 runs up from the current cell, group 1
+                // from the cell above it (where an insertion leads), group 2 from the cell to its left (a deletion).
+                // One iteration then takes: [a gap move] + [the run of alignment moves that follows] + [the gap move
+                // that ends the run] -- about 4-5 path steps per LDS round trip on gappy paths, 21+ on clean ones.
                 for (;;) {
                     ++n_iters;
-                    // lane x: the cell x steps up the diagonal, (i - x, j - x)
-                    const int rho_x = rho - (int)lane;
+                    const uint32_t grp = lane / 21u, x = lane - grp * 21u;        // lane 63: grp 3, idle
+                    const uint32_t di = grp == 1u ? 1u : 0u, dj = grp == 2u ? 1u : 0u;
+                    const int rho_x = rho - (int)di - (int)x;
                     const uint32_t rx = rho_x > 0 ? (uint32_t)rho_x : 0u;
                     const uint32_t lx = rx / R, kx = rx - lx * R;
-                    const int tx = (int)(j - lane) - 1 + (int)lx;
-                    const bool valid = rho_x >= 0 && j > lane && tx >= tmin;
+                    const uint32_t jj = j - dj - x;                                // column of this lane's cell
+                    const int tx = (int)jj - 1 + (int)lx;
+                    const bool valid = grp < 3u && rho_x >= 0 && j > dj + x && tx >= tmin;
                     // all three LDS reads are issued together (one latency): direction word, reference code, read code
                     uint32_t d = 0;
                     bool mt = false;
                     if (valid) {
                         const uint32_t dw = lds_tile[(((uint32_t)tx >> 4) - wlo) * (R * WAVE) + kx * WAVE + lx];
-                        const uint32_t rc = ref_b[(j - 1u - lane) - 4u * cw0];
-                        const uint32_t qc = read_b[i - 1u - lane];
+                        const uint32_t rc = ref_b[(jj - 1u) - 4u * cw0];
+                        const uint32_t qc = read_b[i - 1u - di - x];
                         d = (dw >> (2u * (15u - ((uint32_t)tx & 15u)))) & 3u;
                         mt = rc == qc;
                     }
-                    const uint64_t vmask = __ballot(valid);
-                    if (!(vmask & 1ull)) break;                                    // current cell left the tile / the strip: restage
-                    const uint64_t amask = __ballot(valid && (d & 1u));
-                    uint32_t run = ~amask == 0ull ? 64u : (uint32_t)__builtin_ctzll(~amask);
-                    if (run == 0) {
-                        // the current cell is an insertion or a deletion: H(pred) = H - gap   (:395-406)
-                        const uint32_t d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
+                    const uint64_t vmask = BALLOT(valid);
+                    if (!(vmask & 1ull)) break;                                    // current cell left the window / the strip: restage
+                    const uint64_t amask = BALLOT(valid && (d & 1u));            // alignment chosen
+                    const uint64_t imask = BALLOT(valid && (d & 3u) == 2u);      // insertion chosen (else deletion)
+                    const uint64_t mm = BALLOT(mt);
+                    bool done = false;
+                    uint32_t base = 0;                                             // first lane of the diagonal the run is on
+                    if (!(amask & 1ull)) {
+                        // ---- the current cell is an insertion or a deletion: H(pred) = H - gap   (:395-406) ----
                         begin = (int)j;                                             // :383
                         score -= ugap;
                         uint32_t op;
-                        if (d0 & 2u) { --i; --rho; op = SWMI_DIR_I; } else { --j; op = SWMI_DIR_D; }
+                        if (imask & 1ull) { --i; --rho; op = SWMI_DIR_I; base = 21u; } else { --j; op = SWMI_DIR_D; base = 42u; }
                         if (lane == 0 && n_ops < 4u * A.lds_words) ops_b[n_ops] = (uint8_t)op;
                         n_ops += 1u;
-                    } else {
-                        // a run of alignment moves: H(i-1,j-1) = H - s(ref[j-1], read[i-1])   (:388-394)
-                        const uint64_t mm = __ballot(mt);
-                        const uint32_t cm = lanemask_lt_count(mm) + (mt ? 1u : 0u);          // matches among lanes 0..x
-                        const uint32_t after = score - (cm * umat + (lane + 1u - cm) * umis);   // H after x+1 moves
-                        const uint64_t z = __ballot(lane < run && (int)after <= 0);
-                        if (z) run = (uint32_t)__builtin_ctzll(z) + 1u;              // `while (score > 0)` stops there
-                        score = (uint32_t)__builtin_amdgcn_readlane((int)after, run - 1u);
-                        begin = (int)(j - (run - 1u));
-                        if (lane < run && n_ops + lane < 4u * A.lds_words) ops_b[n_ops + lane] = (uint8_t)SWMI_DIR_A;
-                        n_ops += run; i -= run; j -= run; rho -= (int)run;
+                        if ((int)score <= 0) break;
+                        if (i == 0 || j == 0) { score = 0; break; }
+                        if (rho < 0 || !((vmask >> base) & 1ull)) continue;       // next cell not staged: start over from it
                     }
-                    if ((int)score <= 0) break;
-                    if (i == 0 || j == 0) { score = 0; break; }                      // H is 0 on the border
-                    if (rho < 0) break;                                             // continues in the strip above
+                    // ---- a run of alignment moves on diagonal `base`: H(i-1,j-1) = H - s(ref[j-1], read[i-1])   (:388-394) ----
+                    uint32_t run = (uint32_t)__builtin_ctzll(~((amask >> base) & 0x1FFFFFull));     // 0..21
+                    if (run > 0) {
+                        const uint64_t range = ((1ull << run) - 1ull) << base;
+                        const bool in_run = (range >> lane) & 1ull;
+                        const uint32_t cm = lanemask_lt_count(mm & range) + (mt ? 1u : 0u);   // matches among the run's lanes up to this one
+                        const uint32_t after = score - (cm * umat + (lane - base + 1u - cm) * umis);   // H after this lane's move
+                        const uint64_t z = BALLOT(in_run && (int)after <= 0);
+                        if (z) { run = (uint32_t)__builtin_ctzll(z) - base + 1u; done = true; }   // `while (score > 0)` stops there
+                        score = (uint32_t)__builtin_amdgcn_readlane((int)after, base + run - 1u);
+                        begin = (int)(j - (run - 1u));
+                        if (lane >= base && lane < base + run && n_ops + (lane - base) < 4u * A.lds_words)
+                            ops_b[n_ops + (lane - base)] = (uint8_t)SWMI_DIR_A;
+                        n_ops += run; i -= run; j -= run; rho -= (int)run;
+                        if (done || (int)score <= 0) break;
+                        if (i == 0 || j == 0) { score = 0; break; }
+                        if (rho < 0) break;                                         // continues in the strip above
+                    }
+                    // ---- the gap move that ended the run, if that cell was inspected ----
+                    const uint32_t nxt = base + run;
+                    if (run < 21u && ((vmask >> nxt) & 1ull)) {
+                        begin = (int)j;
+                        score -= ugap;
+                        uint32_t op;
+                        if ((imask >> nxt) & 1ull) { --i; --rho; op = SWMI_DIR_I; } else { --j; op = SWMI_DIR_D; }
+                        if (lane == 0 && n_ops < 4u * A.lds_words) ops_b[n_ops] = (uint8_t)op;
+                        n_ops += 1u;
+                        if ((int)score <= 0) break;
+                        if (i == 0 || j == 0) { score = 0; break; }
+                        if (rho < 0) break;
+                    }
                 }
                 if (A.dbg) tk_walk += __builtin_amdgcn_s_memtime() - tw0;
             }
             n_steps += n_ops;
-            __syncthreads();
+            WAVE_SYNC();
 
             // ---- append the record: header + ops packed 2 bits each (16 per dword) ----
             const uint32_t opw = (n_ops + 15u) / 16u;
@@ -540,7 +719,6 @@ __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDes
             unsigned long long off = 0;
             if (lane == 0) {
                 off = atomicAdd(&A.hdr->used_words, (unsigned long long)words);
-                atomicAdd(&A.hdr->n_records, 1ull);
             }
             off = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(off >> 32)) << 32) |
                   (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)off);
@@ -565,7 +743,7 @@ __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDes
             } else if (lane == 0) {
                 atomicOr(&A.out[pd.out_id].flags, SWMI_F_ARENA_OVF);
             }
-            __syncthreads();
+            WAVE_SYNC();
         }
     }
     if (A.dbg && lane == 0 && slot == 0) {
@@ -576,9 +754,8 @@ __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDes
     }
 }
 
-extern "C" __global__ void __launch_bounds__(WAVE)
-sw_traceback_kernel(const TraceArgs A) {
-    extern __shared__ uint32_t tb_lds[];
+template <int TMODE>
+__device__ __forceinline__ void traceback_entry(const TraceArgs &A, uint32_t *tb_lds) {
     const uint32_t pair = blockIdx.x;
     if (pair >= A.n_pairs) return;
     const uint32_t lane = threadIdx.x;
@@ -588,10 +765,49 @@ sw_traceback_kernel(const TraceArgs A) {
     if (po.flags & (SWMI_F_DEGENERATE | SWMI_F_CELL_OVF)) return;
     if (po.n_cells <= slot) return;
     const uint32_t R = swmi_rows_per_lane(A.reads[pd.read_id].len);
-    if (R == 1)      traceback_pair<1>(A, pd, po, lane, slot, tb_lds);
-    else if (R == 2) traceback_pair<2>(A, pd, po, lane, slot, tb_lds);
-    else if (R == 3) traceback_pair<3>(A, pd, po, lane, slot, tb_lds);
-    else             traceback_pair<4>(A, pd, po, lane, slot, tb_lds);
+    if (R == 1)      traceback_pair<1, TMODE>(A, pd, po, lane, slot, SWMI_TB_SLOTS, tb_lds);
+    else if (R == 2) traceback_pair<2, TMODE>(A, pd, po, lane, slot, SWMI_TB_SLOTS, tb_lds);
+    else if (R == 3) traceback_pair<3, TMODE>(A, pd, po, lane, slot, SWMI_TB_SLOTS, tb_lds);
+    else             traceback_pair<4, TMODE>(A, pd, po, lane, slot, SWMI_TB_SLOTS, tb_lds);
+}
+
+// mode 1, one launch: every wavefront sweeps its pair (scores + checkpoints) and then walks that pair's
+// alignments itself.  No second launch, no grid-wide wait between the two phases: a pair's traceback starts the
+// moment its own sweep ends, so the launch lasts max(sweep_i + walk_i), not max(sweep) + max(walk).
+extern "C" __global__ void __launch_bounds__(WAVE * FILL_WAVES)
+sw_align_fused_kernel(const FusedArgs A) {
+    extern __shared__ uint32_t fused_lds[];
+    fill_entry<SWMI_MODE_SCORE>(A.f);
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t pair = blockIdx.x * FILL_WAVES + wave;
+    if (pair >= A.f.n_pairs) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    const PairDesc pd = A.t.pairs[pair];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's PairOut, cell list and checkpoints have left the CU
+    PairOut po;
+    const uint32_t *op = reinterpret_cast<const uint32_t *>(A.t.out + pd.out_id);
+    po.score = (int32_t)ld_l2(op);
+    po.flags = ld_l2(op + 1);
+    po.n_cells = ((uint64_t)ld_l2(op + 3) << 32) | ld_l2(op + 2);
+    if (po.flags & (SWMI_F_DEGENERATE | SWMI_F_CELL_OVF)) return;
+    uint32_t *lds = fused_lds + wave * (A.t.lds_words + A.t.lds_read_words + SWMI_TB_REFWIN_WORDS + SWMI_CK_BLOCKS * SWMI_RMAX * WAVE);
+    const uint32_t R = swmi_rows_per_lane(A.t.reads[pd.read_id].len);
+    if (R == 1)      traceback_pair<1, 1>(A.t, pd, po, lane, 0u, 1u, lds);
+    else if (R == 2) traceback_pair<2, 1>(A.t, pd, po, lane, 0u, 1u, lds);
+    else if (R == 3) traceback_pair<3, 1>(A.t, pd, po, lane, 0u, 1u, lds);
+    else             traceback_pair<4, 1>(A.t, pd, po, lane, 0u, 1u, lds);
+}
+
+extern "C" __global__ void __launch_bounds__(WAVE)
+sw_traceback_kernel(const TraceArgs A) {
+    extern __shared__ uint32_t tb_lds[];
+    traceback_entry<0>(A, tb_lds);
+}
+
+extern "C" __global__ void __launch_bounds__(WAVE)
+sw_traceback_replay_kernel(const TraceArgs A) {
+    extern __shared__ uint32_t tb_lds[];
+    traceback_entry<1>(A, tb_lds);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -599,14 +815,26 @@ sw_traceback_kernel(const TraceArgs A) {
 // ------------------------------------------------------------------------------------------------
 extern "C" hipError_t swmi_launch_fill(const FillArgs *a, hipStream_t st) {
     if (a->n_pairs == 0) return hipSuccess;
-    hipLaunchKernelGGL(sw_fill_kernel, dim3((a->n_pairs + FILL_WAVES - 1) / FILL_WAVES), dim3(WAVE * FILL_WAVES), 0, st, *a);
+    const dim3 grid((a->n_pairs + FILL_WAVES - 1) / FILL_WAVES), block(WAVE * FILL_WAVES);
+    if (a->mode == 0) hipLaunchKernelGGL(sw_fill_kernel, grid, block, 0, st, *a);
+    else              hipLaunchKernelGGL(sw_fill_score_kernel, grid, block, 0, st, *a);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t swmi_launch_fused(const FusedArgs *a, hipStream_t st) {
+    if (a->f.n_pairs == 0) return hipSuccess;
+    const size_t per_wave = (size_t)a->t.lds_words + a->t.lds_read_words + SWMI_TB_REFWIN_WORDS + (size_t)SWMI_CK_BLOCKS * SWMI_RMAX * WAVE;
+    const dim3 grid((a->f.n_pairs + FILL_WAVES - 1) / FILL_WAVES), block(WAVE * FILL_WAVES);
+    hipLaunchKernelGGL(sw_align_fused_kernel, grid, block, per_wave * FILL_WAVES * sizeof(uint32_t), st, *a);
     return hipGetLastError();
 }
 
 extern "C" hipError_t swmi_launch_traceback(const TraceArgs *a, hipStream_t st) {
     if (a->n_pairs == 0) return hipSuccess;
-    const size_t lds = ((size_t)a->lds_words + a->lds_read_words + SWMI_TB_REFWIN_WORDS +
-                        (size_t)SWMI_TB_BLOCKS * SWMI_RMAX * WAVE) * sizeof(uint32_t);
-    hipLaunchKernelGGL(sw_traceback_kernel, dim3(a->n_pairs, SWMI_TB_SLOTS), dim3(WAVE), lds, st, *a);
+    const size_t tile = (size_t)(a->mode == 0 ? SWMI_TB_BLOCKS : SWMI_CK_BLOCKS) * SWMI_RMAX * WAVE;
+    const size_t lds = ((size_t)a->lds_words + a->lds_read_words + SWMI_TB_REFWIN_WORDS + tile) * sizeof(uint32_t);
+    const dim3 grid(a->n_pairs, SWMI_TB_SLOTS), block(WAVE);
+    if (a->mode == 0) hipLaunchKernelGGL(sw_traceback_kernel, grid, block, lds, st, *a);
+    else              hipLaunchKernelGGL(sw_traceback_replay_kernel, grid, block, lds, st, *a);
     return hipGetLastError();
 }

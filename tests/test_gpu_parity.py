@@ -19,9 +19,13 @@ READ_80 = "AATTTTAGTCTCTCCCTACCCTTTTGGACAGAGCTTCCTGTCCTCTCATTTCACAGGTTATGCAACAGA
 READ_20 = "ACTGACTGACTGACTGACTG"   # EngineerData.java:29
 
 
-@pytest.fixture(scope="module")
-def ctx():
+@pytest.fixture(scope="module", params=[(1, 1), (1, 0), (0, 0)], ids=["mode1-fused", "mode1-two-launches", "mode0-field"])
+def ctx(request):
+    """Every kernel pipeline: mode 1 = score-only sweep + checkpointed replay (default; fused into one launch or as
+    two launches), mode 0 = direction field in HBM."""
     c = sw.Context(0)
+    c.set_option("mode", request.param[0])
+    c.set_option("fuse", request.param[1])
     yield c
     c.close()
 

@@ -31,7 +31,7 @@ class Ins:
         self.text, self.wr, self.rd = text, tuple(wr), tuple(rd)
 
 
-def schedule(R, acgt, strict):
+def schedule(R, acgt, strict, dirs=True):
     ge = "v_cmp_gt_i32_e64" if strict else "v_cmp_ge_i32_e64"
     ins = []
     # phase 1: substitution scores and the diagonal candidates (all from the previous column's values)
@@ -47,17 +47,25 @@ def schedule(R, acgt, strict):
         src = "%[diag]" if k == 0 else f"%[i{k-1}]"
         ins.append(Ins(f"v_add_u32_e32 %[a{k}], %[a{k}], {src}"))
     # phase 2: the dependent chain down the lane's rows
-    for k in range(R):
-        up = "%[up]" if k == 0 else f"%[o{k-1}]"
-        ins.append(Ins(f"{ge} %[sI], {up}, %[i{k}]", wr=["sI"]))
-        if k > 0:
-            ins.append(Ins(f"v_addc_co_u32_e64 %[acc{k-1}], vcc, %[acc{k-1}], %[acc{k-1}], %[sA]", rd=["sA"]))
-        ins.append(Ins(f"v_max_i32_e32 %[t], {up}, %[i{k}]"))
-        ins.append(Ins(f"v_add_u32_e32 %[t], %[gap], %[t]"))
-        ins.append(Ins(f"{ge} %[sA], %[a{k}], %[t]", wr=["sA"]))
-        ins.append(Ins(f"v_addc_co_u32_e64 %[acc{k}], vcc, %[acc{k}], %[acc{k}], %[sI]", rd=["sI"]))
-        ins.append(Ins(f"v_max3_i32 %[o{k}], %[a{k}], %[t], 0"))
-    ins.append(Ins(f"v_addc_co_u32_e64 %[acc{R-1}], vcc, %[acc{R-1}], %[acc{R-1}], %[sA]", rd=["sA"]))
+    if not dirs:
+        # score-only variant (checkpoint/recompute mode): 5 VALU per cell, no direction bits
+        for k in range(R):
+            up = "%[up]" if k == 0 else f"%[o{k-1}]"
+            ins.append(Ins(f"v_max_i32_e32 %[t], {up}, %[i{k}]"))
+            ins.append(Ins(f"v_add_u32_e32 %[t], %[gap], %[t]"))
+            ins.append(Ins(f"v_max3_i32 %[o{k}], %[a{k}], %[t], 0"))
+    else:
+        for k in range(R):
+            up = "%[up]" if k == 0 else f"%[o{k-1}]"
+            ins.append(Ins(f"{ge} %[sI], {up}, %[i{k}]", wr=["sI"]))
+            if k > 0:
+                ins.append(Ins(f"v_addc_co_u32_e64 %[acc{k-1}], vcc, %[acc{k-1}], %[acc{k-1}], %[sA]", rd=["sA"]))
+            ins.append(Ins(f"v_max_i32_e32 %[t], {up}, %[i{k}]"))
+            ins.append(Ins(f"v_add_u32_e32 %[t], %[gap], %[t]"))
+            ins.append(Ins(f"{ge} %[sA], %[a{k}], %[t]", wr=["sA"]))
+            ins.append(Ins(f"v_addc_co_u32_e64 %[acc{k}], vcc, %[acc{k}], %[acc{k}], %[sI]", rd=["sI"]))
+            ins.append(Ins(f"v_max3_i32 %[o{k}], %[a{k}], %[t], 0"))
+        ins.append(Ins(f"v_addc_co_u32_e64 %[acc{R-1}], vcc, %[acc{R-1}], %[acc{R-1}], %[sA]", rd=["sA"]))
     # hazard pass
     out = []
     last_wr = {}
@@ -81,30 +89,33 @@ def schedule(R, acgt, strict):
     return out
 
 
-def emit(R, acgt, strict):
-    body = schedule(R, acgt, strict)
+def emit(R, acgt, strict, dirs=True):
+    body = schedule(R, acgt, strict, dirs)
     n_valu = sum(1 for i in body if not i.text.startswith("s_nop"))
     n_nop = len(body) - n_valu
     lines = []
-    lines.append(f"// R={R} {'ACGT' if acgt else 'GENERIC'} {'STRICT' if strict else 'SERIAL'}: "
+    lines.append(f"// R={R} {'ACGT' if acgt else 'GENERIC'} {'STRICT' if strict else 'SERIAL'} {'DIRS' if dirs else 'SCORE-ONLY'}: "
                  f"{n_valu} VALU ({n_valu / R:.1f}/cell), {n_nop} s_nop")
-    lines.append("template <> struct CellsAsm<%d, %s, %s> {" % (R, "true" if acgt else "false", "true" if strict else "false"))
+    lines.append("template <> struct CellsAsm<%d, %s, %s, %s> {" % (R, "true" if acgt else "false", "true" if strict else "false", "true" if dirs else "false"))
     lines.append("    static __device__ __forceinline__ void step(const int (&hin)[%d], int (&hout)[%d], uint32_t (&acc)[%d], const int (&q)[%d]," % (R, R, R, R))
     lines.append("                                                int rb, int diag, int up, int gap, int vmat, int vmis) {")
     lines.append("        int " + ", ".join(f"a{k}" for k in range(R)) + ", t;")
-    sg = ["sI", "sA"] + ([] if acgt else [f"m{k}" for k in range(R)])
-    lines.append("        unsigned long long " + ", ".join(sg) + ";")
+    sg = (["sI", "sA"] if dirs else []) + ([] if acgt else [f"m{k}" for k in range(R)])
+    if sg:
+        lines.append("        unsigned long long " + ", ".join(sg) + ";")
     lines.append("        asm volatile(")
     for i in body:
         lines.append(f'            "{i.text}\\n\\t"')
-    outs = [f'[o{k}] "=&v"(hout[{k}])' for k in range(R)] + [f'[acc{k}] "+v"(acc[{k}])' for k in range(R)]
+    outs = [f'[o{k}] "=&v"(hout[{k}])' for k in range(R)] + ([f'[acc{k}] "+v"(acc[{k}])' for k in range(R)] if dirs else [])
     outs += [f'[a{k}] "=&v"(a{k})' for k in range(R)] + ['[t] "=&v"(t)'] + [f'[{s}] "=&s"({s})' for s in sg]
     ins_ = [f'[i{k}] "v"(hin[{k}])' for k in range(R)] + [f'[q{k}] "v"(q[{k}])' for k in range(R)] + ['[rb] "v"(rb)', '[diag] "v"(diag)', '[up] "v"(up)', '[gap] "s"(gap)']
     if not acgt:
         ins_ += ['[vmat] "v"(vmat)', '[vmis] "v"(vmis)']
     lines.append("            : " + ", ".join(outs))
     lines.append("            : " + ", ".join(ins_))
-    lines.append('            : "vcc");')
+    lines.append('            : "vcc");' if dirs else '            : );')
+    if not dirs:
+        lines.append("        (void)acc;")
     if acgt:
         lines.append("        (void)vmat; (void)vmis;")
     lines.append("    }")
@@ -118,12 +129,14 @@ def main():
     parts = ["// GENERATED by tools/gen_cells.py -- do not edit; re-run the script instead.",
              "// Direction bits pushed per cell: first bI (insertion >= deletion), then bA (alignment >= both):",
              "// the 2-bit code is (bI << 1) | bA; traceback decodes A if bit0, else I if bit1, else D.",
-             "template <int R, bool ACGT, bool STRICT> struct CellsAsm;", ""]
+             "template <int R, bool ACGT, bool STRICT, bool DIRS> struct CellsAsm;", ""]
     for R in (1, 2, 3, 4):
         for acgt in (True, False):
             for strict in (False, True):
-                parts.append(emit(R, acgt, strict))
+                parts.append(emit(R, acgt, strict, True))
                 parts.append("")
+            parts.append(emit(R, acgt, False, False))     # scores do not depend on the tie order
+            parts.append("")
     with open(path, "w") as f:
         f.write("\n".join(parts))
     print("wrote", path)
