@@ -23,6 +23,7 @@ v_cmp_eq_u32 + v_cndmask_b32.
 import os
 import sys
 
+INTERLEAVE = os.environ.get("SWMI_GEN_INTERLEAVE", "1") != "0"
 HAZARD = 2   # wait states: VALU writes SGPR -> VALU reads that SGPR (gfx940/gfx950)
 
 
@@ -48,12 +49,31 @@ def schedule(R, acgt, strict, dirs=True):
         ins.append(Ins(f"v_add_u32_e32 %[a{k}], %[a{k}], {src}"))
     # phase 2: the dependent chain down the lane's rows
     if not dirs:
-        # score-only variant (checkpoint/recompute mode): 5 VALU per cell, no direction bits
+        # score-only variant (checkpoint/recompute mode): 5 VALU per cell, no direction bits.  The row chain
+        # max -> add -> max3 is strictly dependent; the independent profile lookups of the rows below are woven
+        # into it (phase 1 above only emitted row 0's) so that dependent instructions are not back to back.
+        chain = []
         for k in range(R):
             up = "%[up]" if k == 0 else f"%[o{k-1}]"
-            ins.append(Ins(f"v_max_i32_e32 %[t], {up}, %[i{k}]"))
-            ins.append(Ins(f"v_add_u32_e32 %[t], %[gap], %[t]"))
-            ins.append(Ins(f"v_max3_i32 %[o{k}], %[a{k}], %[t], 0"))
+            chain.append([Ins(f"v_max_i32_e32 %[t], {up}, %[i{k}]"),
+                          Ins(f"v_add_u32_e32 %[t], %[gap], %[t]"),
+                          Ins(f"v_max3_i32 %[o{k}], %[a{k}], %[t], 0")])
+        if INTERLEAVE and acgt:
+            # ins currently holds: bfe x R, add x R.  Rebuild: row 0 lookup first, then weave.
+            look = [[Ins(f"v_bfe_i32 %[a{k}], %[q{k}], %[rb], 8"),
+                     Ins(f"v_add_u32_e32 %[a{k}], %[a{k}], " + ("%[diag]" if k == 0 else f"%[i{k-1}]"))] for k in range(R)]
+            ins = list(look[0])
+            pending = [x for k in range(1, R) for x in look[k]]
+            for k in range(R):
+                for c in chain[k]:
+                    ins.append(c)
+                    if pending:
+                        # row k+1's a must be complete before its max3: keep at least its two lookups ahead
+                        ins.append(pending.pop(0))
+            ins.extend(pending)
+        else:
+            for k in range(R):
+                ins.extend(chain[k])
     else:
         for k in range(R):
             up = "%[up]" if k == 0 else f"%[o{k-1}]"
