@@ -48,16 +48,23 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal on a one-GPU box: SWMI_BENCH_ONE_GPU=1 puts every rank on GPU 0 and uses gloo for the reduce
+    one_gpu = os.environ.get("SWMI_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     elif args.gpus > 1:
         print("bench.py --gpus %d must be launched through torch.distributed.run" % args.gpus, file=sys.stderr)
         sys.exit(2)
     else:
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cpu") if (one_gpu and world > 1) else torch.device("cuda", local_rank)
 
     # ---- synthetic inputs: shard `rank` of a world*n_refs reference set, the read of shard 0 --------------
     refs0, reads = synth.config_1k(args.n_refs, args.ref_len, args.read_len, seed=1)
@@ -78,11 +85,13 @@ def main():
     batch = ctx.upload(refs, reads)          # H2D happens here, outside the timed region
     params = sw.make_params()
 
+    import numpy as np
+    gids = np.arange(id0, id0 + len(refs), dtype=np.int64)
+
     def step():
         batch.run(params)
-        totals = [batch.ref_total(r) for r in range(len(refs))] if world > 1 else None
-        if world > 1:
-            return swd.global_max_with_ties(totals, range(id0, id0 + len(refs)), device=dev)
+        if world > 1:      # the path's one exchange step: max total + its references over RCCL
+            return swd.global_max_with_ties(batch.ref_totals(), gids, device=dev)
         return None
 
     def sync():
@@ -108,7 +117,7 @@ def main():
     elapsed = float(tmax.item())
 
     # ---- parity spot check on the bench inputs (outside the timed region) ---------------------------------
-    winner = max(range(len(refs)), key=lambda r: batch.ref_total(r))
+    winner = int(np.argmax(batch.ref_totals()))
 
     if rank == 0:
         total_cells = cells_rank * world * args.steps

@@ -123,6 +123,8 @@ int      swmi_pair_alignment(swmi_batch *b, uint64_t pair, uint64_t k,
 /* ---- MapRef view: per reference, over all reads (Distribution.java:403-436) ------ */
 /* total = sum over reads of the pair scores (Java int, wrapping) (:424). */
 int      swmi_ref_total(const swmi_batch *b, uint32_t ref, int32_t *total);
+/* all n_refs totals at once into totals[n_refs] (what the driver's max/top-K reduce consumes, :341-353) */
+int      swmi_ref_totals(const swmi_batch *b, int32_t *totals, uint32_t n);
 /* matchSites = the reads' alignment lists concatenated in read order (:425), then
  * stably sorted by ascending begin (:428, MatchSiteComp :691-694). */
 int      swmi_ref_n_match_sites(swmi_batch *b, uint32_t ref, uint64_t *n);

@@ -54,6 +54,7 @@ SYMBOLS = [
                                       C.POINTER(C.c_int32), C.POINTER(C.c_char_p), C.POINTER(C.c_char_p),
                                       C.POINTER(C.c_uint32)]),
     ("swmi_ref_total", C.c_int, [_P, C.c_uint32, C.POINTER(C.c_int32)]),
+    ("swmi_ref_totals", C.c_int, [_P, C.POINTER(C.c_int32), C.c_uint32]),
     ("swmi_ref_n_match_sites", C.c_int, [_P, C.c_uint32, _u64p]),
     ("swmi_ref_match_site", C.c_int, [_P, C.c_uint32, C.c_uint64, C.POINTER(C.c_int32), C.POINTER(C.c_char_p),
                                       C.POINTER(C.c_char_p), C.POINTER(C.c_uint32)]),

@@ -102,6 +102,13 @@ class Batch:
         check(self._lib.swmi_ref_total(self._h, ref, C.byref(v)))
         return v.value
 
+    def ref_totals(self):
+        """numpy int32 array of every reference's total (one native call)."""
+        import numpy as np
+        out = np.empty(self.n_refs, dtype=np.int32)
+        check(self._lib.swmi_ref_totals(self._h, out.ctypes.data_as(C.POINTER(C.c_int32)), self.n_refs))
+        return out
+
     def ref_match_sites(self, ref):
         n = C.c_uint64()
         check(self._lib.swmi_ref_n_match_sites(self._h, ref, C.byref(n)))

@@ -893,6 +893,19 @@ extern "C" int swmi_ref_total(const swmi_batch *b, uint32_t ref, int32_t *total)
     return SWMI_OK;
 }
 
+extern "C" int swmi_ref_totals(const swmi_batch *b, int32_t *totals, uint32_t n) {
+    if (!b || !totals) return fail(SWMI_ERR_INVALID, "null argument");
+    if (!b->has_run) return fail(SWMI_ERR_INVALID, "batch has no results (run it first)");
+    if (n != b->n_refs) return fail(SWMI_ERR_RANGE, "totals has %u entries, the batch has %u references", n, b->n_refs);
+    for (uint32_t r = 0; r < b->n_refs; r++) {
+        uint32_t t = 0;
+        const PairRes *pr = b->pairs.data() + (uint64_t)r * b->n_reads;
+        for (uint32_t q = 0; q < b->n_reads; q++) t += (uint32_t)pr[q].score;
+        totals[r] = (int32_t)t;
+    }
+    return SWMI_OK;
+}
+
 static void build_ref_view(swmi_batch *b, uint32_t ref) {
     if (b->ref_view_ready[ref]) return;
     std::vector<SiteRef> &v = b->ref_sites[ref];

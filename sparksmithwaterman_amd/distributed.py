@@ -24,30 +24,32 @@ def shard_references(refs, rank, world):
 
 def global_max_with_ties(local_totals, global_ids, device=None, group=None, cap=64):
     """Control-path reduce across ranks (Distribution.java:600-613): returns (max_total, sorted ids of every
-    reference whose total equals it).  local_totals/global_ids: equal-length int sequences of this rank's shard.
-    `max` starts at 0 like the reference's (`int max = 0`, :573), so totals below 0 never win."""
+    reference whose total equals it).  local_totals/global_ids: equal-length int sequences (or numpy arrays) of
+    this rank's shard.  `max` starts at 0 like the reference's (`int max = 0`, :573), so totals below 0 never win.
+    Two tiny collectives: all_reduce(MAX) of one int64, all_gather of cap+1 int64 per rank."""
+    import numpy as np
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    t = torch.as_tensor(list(local_totals), dtype=torch.int64)
-    ids = torch.as_tensor(list(global_ids), dtype=torch.int64)
-    local_best = int(t.max()) if t.numel() else 0
-    best = torch.tensor([max(local_best, 0)], dtype=torch.int64, device=device)
+    t = np.asarray(local_totals, dtype=np.int64)
+    ids = np.asarray(global_ids, dtype=np.int64)
+    local_best = int(t.max()) if t.size else 0
+    gbest = max(local_best, 0)
     if world > 1:
+        best = torch.tensor([gbest], dtype=torch.int64, device=device)
         dist.all_reduce(best, op=dist.ReduceOp.MAX, group=group)
-    gbest = int(best.item())
-    mine = ids[t == gbest][:cap] if t.numel() else ids[:0]
-    payload = torch.full((cap + 1,), -1, dtype=torch.int64, device=device)
-    payload[0] = mine.numel()
-    if mine.numel():
-        payload[1:1 + mine.numel()] = mine.to(payload.device)
-    if world > 1:
-        gathered = [torch.empty_like(payload) for _ in range(world)]
-        dist.all_gather(gathered, payload, group=group)
-    else:
-        gathered = [payload]
+        gbest = int(best.item())
+    mine = ids[t == gbest][:cap] if t.size else ids[:0]
+    if world == 1:
+        return gbest, sorted(int(x) for x in mine)
+    pay = np.full(cap + 1, -1, dtype=np.int64)
+    pay[0] = mine.size
+    pay[1:1 + mine.size] = mine
+    payload = torch.from_numpy(pay).to(device) if device is not None else torch.from_numpy(pay)
+    gathered = [torch.empty_like(payload) for _ in range(world)]
+    dist.all_gather(gathered, payload, group=group)
+    g = torch.stack(gathered).cpu().numpy()
     winners = []
-    for g in gathered:
-        g = g.cpu()
-        winners.extend(int(x) for x in g[1:1 + int(g[0])])
+    for row in g:
+        winners.extend(int(x) for x in row[1:1 + int(row[0])])
     return gbest, sorted(winners)
 
 
