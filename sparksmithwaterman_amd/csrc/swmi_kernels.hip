@@ -116,7 +116,7 @@ template <int R, bool ACGT, bool STRICT, bool DIRS> using Cells = CellsAsm<R, AC
 // What a 16-step block does besides the scores:
 //   SWMI_MODE_FIELD   fill, direction bits packed and stored to HBM, tied maxima tracked          (mode 0 fill kernel)
 //   SWMI_MODE_SCORE   fill, scores only (5 VALU per cell) + lane-state checkpoints, maxima tracked (mode 1 fill kernel)
-//   SWMI_MODE_REPLAY  a 64-step window re-swept from a checkpoint, direction bits to LDS, nothing tracked (mode 1 traceback)
+//   SWMI_MODE_REPLAY  a checkpoint-to-checkpoint window re-swept, direction bits to LDS, nothing tracked (mode 1 traceback)
 #define SWMI_MODE_FIELD  0
 #define SWMI_MODE_SCORE  1
 #define SWMI_MODE_REPLAY 2
@@ -459,7 +459,7 @@ sw_fill_score_kernel(const FillArgs A) { fill_entry<SWMI_MODE_SCORE>(A); }
 //  * the wave brings a TILE of the direction field -- every cell whose anti-diagonal step lies in a window
 //    of 16-step blocks, all 64*R row slots of the strip -- into LDS, plus the matching window of reference
 //    codes and the whole read.  Mode 0 copies it from the HBM direction field (16 blocks, coalesced 256 B
-//    loads, all in flight at once); mode 1 RE-SWEEPS 4 blocks (64 steps) from the lane-state checkpoint the
+//    loads, all in flight at once); mode 1 RE-SWEEPS SWMI_CK_BLOCKS blocks from the lane-state checkpoint the
 //    score-only fill left behind, this time with the direction bits (the same instruction stream as the
 //    mode-0 fill), which is cheaper than having every pair pay 4 more VALU per cell in the fill;
 //  * it then advances by RUNS: lane x looks at the cell x steps up the current diagonal, a ballot gives the

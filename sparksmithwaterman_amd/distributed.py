@@ -3,8 +3,8 @@
 The reference data-parallelises over references (`sc.parallelize(list).mapToPair(new MapRef())`,
 src/sw/Distribution.java:337-338) and then reduces to the best total(s) on the driver (:341-353; control-path
 semantics :600-613).  Here every rank aligns its own shard of references against the full read set with no
-data-path collective; the reduce is an all-reduce(max) of one int32 plus an all-gather of the ranks' few
-winners -- bytes over xGMI, latency-bound by design.  Backend "nccl" is RCCL on ROCm; "gloo" in CPU tests.
+data-path collective; the reduce is one all-gather of every rank's {local max, its few winners} -- bytes over
+xGMI, latency-bound by design.  Backend "nccl" is RCCL on ROCm; "gloo" in CPU tests.
 """
 import torch
 import torch.distributed as dist
@@ -26,30 +26,33 @@ def global_max_with_ties(local_totals, global_ids, device=None, group=None, cap=
     """Control-path reduce across ranks (Distribution.java:600-613): returns (max_total, sorted ids of every
     reference whose total equals it).  local_totals/global_ids: equal-length int sequences (or numpy arrays) of
     this rank's shard.  `max` starts at 0 like the reference's (`int max = 0`, :573), so totals below 0 never win.
-    Two tiny collectives: all_reduce(MAX) of one int64, all_gather of cap+1 int64 per rank."""
+
+    ONE collective: every rank contributes {its local max, the ids reaching it} (cap+2 int64 = 528 B) to an
+    all-gather; the global max and its references follow locally and identically on every rank.  (A separate
+    all-reduce(max) first would cost a second latency-bound round trip for the same information.)"""
     import numpy as np
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     t = np.asarray(local_totals, dtype=np.int64)
     ids = np.asarray(global_ids, dtype=np.int64)
-    local_best = int(t.max()) if t.size else 0
-    gbest = max(local_best, 0)
-    if world > 1:
-        best = torch.tensor([gbest], dtype=torch.int64, device=device)
-        dist.all_reduce(best, op=dist.ReduceOp.MAX, group=group)
-        gbest = int(best.item())
-    mine = ids[t == gbest][:cap] if t.size else ids[:0]
+    local_best = max(int(t.max()), 0) if t.size else 0
+    mine = ids[t == local_best][:cap] if t.size else ids[:0]
     if world == 1:
-        return gbest, sorted(int(x) for x in mine)
-    pay = np.full(cap + 1, -1, dtype=np.int64)
-    pay[0] = mine.size
-    pay[1:1 + mine.size] = mine
-    payload = torch.from_numpy(pay).to(device) if device is not None else torch.from_numpy(pay)
+        return local_best, sorted(int(x) for x in mine)
+    pay = np.full(cap + 2, -1, dtype=np.int64)
+    pay[0] = local_best
+    pay[1] = mine.size
+    pay[2:2 + mine.size] = mine
+    payload = torch.from_numpy(pay)
+    if device is not None:
+        payload = payload.to(device)
     gathered = [torch.empty_like(payload) for _ in range(world)]
     dist.all_gather(gathered, payload, group=group)
     g = torch.stack(gathered).cpu().numpy()
+    gbest = int(g[:, 0].max())
     winners = []
     for row in g:
-        winners.extend(int(x) for x in row[1:1 + int(row[0])])
+        if int(row[0]) == gbest:
+            winners.extend(int(x) for x in row[2:2 + int(row[1])])
     return gbest, sorted(winners)
 
 
