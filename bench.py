@@ -88,9 +88,15 @@ def main():
     import numpy as np
     gids = np.arange(id0, id0 + len(refs), dtype=np.int64)
 
+    reducer = None
+    if world > 1 and not one_gpu:
+        reducer = swd.MaxReducer(dev)          # buffers allocated once; one RCCL all-gather per step
+
     def step():
         batch.run(params)
-        if world > 1:      # the path's one exchange step: max total + its references over RCCL
+        if world > 1:      # the path's one exchange step: max total + its references
+            if reducer is not None:
+                return reducer(batch.ref_totals(), gids)
             return swd.global_max_with_ties(batch.ref_totals(), gids, device=dev)
         return None
 

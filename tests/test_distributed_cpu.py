@@ -25,6 +25,9 @@ def _worker(rank, world, port, q):
     best, winners = swd.global_max_with_ties(totals_all[lo:hi], range(lo, hi))
     topk = swd.global_top_k(totals_all[lo:hi], range(lo, hi), 4)
     neg = swd.global_max_with_ties([-3, -1], [lo, lo + 1])     # `int max = 0`: negative totals never win
+    red = swd.MaxReducer("cpu")                                 # the preallocated-buffer form bench.py uses over RCCL
+    assert red(totals_all[lo:hi], list(range(lo, hi))) == (best, winners)
+    assert red([-3, -1], [lo, lo + 1]) == (0, [])
     q.put((rank, best, winners, topk, neg))
     dist.destroy_process_group()
 
