@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--ref-len", type=int, default=2000)
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--d2h-copy", action="store_true", help="fetch results with a D2H copy instead of zero-copy writes to pinned memory")
     ap.add_argument("--fuse", action="store_true", help="mode 1 as ONE launch (sweep + replay + walk per wavefront)")
     ap.add_argument("--mode", type=int, default=None, help="kernel pipeline: 1 = score-only sweep + replay (default), 0 = HBM direction field")
     args = ap.parse_args()
@@ -80,6 +81,8 @@ def main():
         ctx.set_option("mode", args.mode)
     if args.fuse:
         ctx.set_option("fuse", 1)
+    if args.d2h_copy:
+        ctx.set_option("zero_copy", 0)
     mode = 1 if args.mode is None else args.mode
     kernel_name = "sw_fill_kernel" if mode == 0 else ("sw_align_fused_kernel" if args.fuse else "sw_fill_score_kernel")
     batch = ctx.upload(refs, reads)          # H2D happens here, outside the timed region

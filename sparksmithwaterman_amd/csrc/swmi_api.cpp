@@ -71,17 +71,20 @@ struct DevBuf {
 };
 
 struct PinnedBuf {
-    void *p = nullptr;
+    void *p = nullptr;      // host address
+    void *dp = nullptr;     // the same memory as the GPU addresses it (zero-copy results)
     size_t cap = 0;
     int reserve(size_t bytes) {
         if (bytes <= cap) return SWMI_OK;
-        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
-        hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+        if (p) { (void)hipHostFree(p); p = nullptr; dp = nullptr; cap = 0; }
+        hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocMapped);
         if (e != hipSuccess) { p = nullptr; return fail(SWMI_ERR_NOMEM, "hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); }
+        e = hipHostGetDevicePointer(&dp, p, 0);
+        if (e != hipSuccess) { (void)hipHostFree(p); p = nullptr; return fail(SWMI_ERR_HIP, "hipHostGetDevicePointer: %s", hipGetErrorString(e)); }
         cap = bytes;
         return SWMI_OK;
     }
-    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; dp = nullptr; cap = 0; }
 };
 
 // ------------------------------------------------------------------------------------------
@@ -96,6 +99,7 @@ struct swmi_ctx {
     uint64_t max_workspace_bytes = 32ull << 30;
     int profiling = 0;
     uint32_t mode = 1;                      // 0 = direction field in HBM, 1 = score-only sweep + checkpointed replay
+    int zero_copy = 1;                      // kernels write results straight into pinned host memory (no D2H copy)
     int fuse = 0;                           // mode 1: sweep and walk in one launch (off: measured slower whenever some pairs
                                             // have several tied maxima, because their walks then serialise on one wavefront)
     uint64_t arena_words_per_pair = 48;     // first guess of the record arena, grows on demand
@@ -229,6 +233,8 @@ extern "C" int swmi_set_option(swmi_ctx *ctx, const char *name, int64_t value) {
     } else if (!strcmp(name, "mode")) {
         if (value != 0 && value != 1) return fail(SWMI_ERR_INVALID, "mode must be 0 or 1");
         ctx->mode = (uint32_t)value;
+    } else if (!strcmp(name, "zero_copy")) {
+        ctx->zero_copy = value != 0;
     } else if (!strcmp(name, "fuse")) {
         ctx->fuse = value != 0;
     } else if (!strcmp(name, "profiling")) {
@@ -503,6 +509,18 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
         ta.mode = ctx->mode;
         ta.pad2 = 0;
         ta.lds_read_words = lds_read_words;
+        ta.out_host = nullptr;
+        ta.ovf_host = nullptr;
+        const bool zc = ctx->zero_copy != 0;
+        if (zc) {
+            // results land in pinned host memory while the kernel runs: [overflow word .. | PairOut x np | arena]
+            if ((rc = b->h_result.reserve(a_off + arena_cap * 4))) return rc;
+            uint8_t *hd = (uint8_t *)b->h_result.dp;
+            *(volatile uint32_t *)b->h_result.p = 0u;
+            ta.ovf_host = (uint32_t *)hd;
+            ta.out_host = (PairOut *)(hd + result_out_off());
+            ta.arena = (uint32_t *)(hd + a_off);
+        }
         ta.dbg = nullptr;
         if (getenv("SWMI_DEBUG_FILL")) {
             if ((rc = b->d_dbg2.reserve(np * 32))) return rc;
@@ -534,12 +552,14 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
             if (ctx->profiling) HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
         }
 
-        // one D2H of header + pair outputs + as much of the arena as the previous run used (plus slack);
-        // the rare remainder is fetched after the header has been read
+        // without zero-copy: one D2H of header + pair outputs + as much of the arena as the previous run used
+        // (plus slack); the rare remainder is fetched after the header has been read
         const uint64_t copy_words = std::min<uint64_t>(arena_cap, std::max<uint64_t>(256, np * ctx->arena_copy_wpp));
         const size_t copy_bytes = a_off + copy_words * 4;
-        if ((rc = b->h_result.reserve(a_off + arena_cap * 4))) return rc;
-        HIP_TRY(hipMemcpyAsync(b->h_result.p, res, copy_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        if (!zc) {
+            if ((rc = b->h_result.reserve(a_off + arena_cap * 4))) return rc;
+            HIP_TRY(hipMemcpyAsync(b->h_result.p, res, copy_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        }
         if (ctx->profiling) HIP_TRY(hipEventRecord(ctx->ev[4], ctx->stream));
         const auto c1 = std::chrono::steady_clock::now();
         HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -572,20 +592,50 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
                     np, (double)ev / np, evmax, (double)cyc / np, cmin, cmax);
         }
         const uint8_t *h = (const uint8_t *)b->h_result.p;
+        ArenaHdr hdr_copy{};
         const ArenaHdr *hdr = (const ArenaHdr *)h;
-        if (hdr->used_words > arena_cap) {         // records were dropped: grow to the exact need and redo the traceback
-            saved_outs.assign(h + result_out_off(), h + result_out_off() + np * sizeof(PairOut));
+        bool overflow;
+        if (zc) {
+            overflow = *(const volatile uint32_t *)h != 0u;
+            if (overflow) {        // rare: how much was needed is in the device-side header
+                HIP_TRY(hipMemcpy(&hdr_copy, res, sizeof hdr_copy, hipMemcpyDeviceToHost));
+                hdr = &hdr_copy;
+            }
+        } else {
+            overflow = hdr->used_words > arena_cap;
+        }
+        if (overflow) {            // records were dropped: grow to the exact need and redo the traceback
+            if (zc) {
+                saved_outs.resize(np * sizeof(PairOut));
+                HIP_TRY(hipMemcpy(saved_outs.data(), res + result_out_off(), saved_outs.size(), hipMemcpyDeviceToHost));
+            } else {
+                saved_outs.assign(h + result_out_off(), h + result_out_off() + np * sizeof(PairOut));
+            }
             for (size_t k = 0; k < np; k++) ((PairOut *)saved_outs.data())[k].flags &= ~SWMI_F_ARENA_OVF;
             arena_cap = hdr->used_words + 1024;
             ctx->arena_words_per_pair = std::max<uint64_t>(ctx->arena_words_per_pair, arena_cap / np + 1);
             continue;
         }
-        arena_used = hdr->used_words;
-        if (arena_used > copy_words)
-            HIP_TRY(hipMemcpy((uint8_t *)b->h_result.p + copy_bytes, res + copy_bytes, (arena_used - copy_words) * 4,
-                              hipMemcpyDeviceToHost));
-        ctx->arena_copy_wpp = arena_used * 5 / (4 * np) + 2;
         outs.assign((const PairOut *)(h + result_out_off()), (const PairOut *)(h + result_out_off()) + np);
+        if (zc) {
+            // the records are contiguous from word 0; how many there are follows from the pair outputs
+            uint64_t expect = 0, at = 0;
+            for (auto &o : outs)
+                if (!(o.flags & (SWMI_F_DEGENERATE | SWMI_F_CELL_OVF))) expect += o.n_cells;
+            const uint32_t *aw = (const uint32_t *)(h + a_off);
+            for (uint64_t k = 0; k < expect; k++) {
+                if (at + SWMI_ALNREC_WORDS > arena_cap) return fail(SWMI_ERR_HIP, "record stream overruns the arena");
+                at += SWMI_ALNREC_WORDS + ((uint64_t)aw[at + 5] + 15) / 16;
+            }
+            if (at > arena_cap) return fail(SWMI_ERR_HIP, "record stream overruns the arena");
+            arena_used = at;
+        } else {
+            arena_used = hdr->used_words;
+            if (arena_used > copy_words)
+                HIP_TRY(hipMemcpy((uint8_t *)b->h_result.p + copy_bytes, res + copy_bytes, (arena_used - copy_words) * 4,
+                                  hipMemcpyDeviceToHost));
+            ctx->arena_copy_wpp = arena_used * 5 / (4 * np) + 2;
+        }
         arena_copy.assign((const uint32_t *)(h + a_off), (const uint32_t *)(h + a_off) + arena_used);
         for (auto &o : outs) o.flags &= ~SWMI_F_ARENA_OVF;
         rs.copyout_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - c2).count();

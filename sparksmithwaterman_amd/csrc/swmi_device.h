@@ -124,6 +124,8 @@ struct TraceArgs {
     uint32_t        lds_read_words;   // LDS dwords reserved for the longest read's codes
     unsigned long long *dbg;     // optional diagnostics: per pair {ticks, walk ticks, steps, tiles}
     const int32_t  *seam;        // mode 1: strip seam rows for the replay of multi-strip pairs
+    PairOut        *out_host;    // zero-copy results: host-mapped mirror of out[] (written by slot 0 of every pair), or null
+    uint32_t       *ovf_host;    // zero-copy results: set to 1 when a record did not fit the (host-mapped) arena
     uint32_t        mode;        // 0 = read the HBM direction field, 1 = replay windows from checkpoints
     uint32_t        pad2;
 };

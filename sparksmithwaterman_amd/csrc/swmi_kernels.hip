@@ -742,6 +742,7 @@ __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDes
                 }
             } else if (lane == 0) {
                 atomicOr(&A.out[pd.out_id].flags, SWMI_F_ARENA_OVF);
+                if (A.ovf_host) *A.ovf_host = 1u;
             }
             WAVE_SYNC();
         }
@@ -762,6 +763,7 @@ __device__ __forceinline__ void traceback_entry(const TraceArgs &A, uint32_t *tb
     const uint32_t slot = blockIdx.y;
     const PairDesc pd = A.pairs[pair];
     const PairOut po = A.out[pd.out_id];
+    if (A.out_host && slot == 0 && lane == 0) A.out_host[pd.out_id] = po;      // result straight into pinned host memory
     if (po.flags & (SWMI_F_DEGENERATE | SWMI_F_CELL_OVF)) return;
     if (po.n_cells <= slot) return;
     const uint32_t R = swmi_rows_per_lane(A.reads[pd.read_id].len);
@@ -789,6 +791,7 @@ sw_align_fused_kernel(const FusedArgs A) {
     po.score = (int32_t)ld_l2(op);
     po.flags = ld_l2(op + 1);
     po.n_cells = ((uint64_t)ld_l2(op + 3) << 32) | ld_l2(op + 2);
+    if (A.t.out_host && lane == 0) A.t.out_host[pd.out_id] = po;
     if (po.flags & (SWMI_F_DEGENERATE | SWMI_F_CELL_OVF)) return;
     uint32_t *lds = fused_lds + wave * (A.t.lds_words + A.t.lds_read_words + SWMI_TB_REFWIN_WORDS + SWMI_CK_BLOCKS * SWMI_RMAX * WAVE);
     const uint32_t R = swmi_rows_per_lane(A.t.reads[pd.read_id].len);

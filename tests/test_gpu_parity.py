@@ -19,13 +19,15 @@ READ_80 = "AATTTTAGTCTCTCCCTACCCTTTTGGACAGAGCTTCCTGTCCTCTCATTTCACAGGTTATGCAACAGA
 READ_20 = "ACTGACTGACTGACTGACTG"   # EngineerData.java:29
 
 
-@pytest.fixture(scope="module", params=[(1, 1), (1, 0), (0, 0)], ids=["mode1-fused", "mode1-two-launches", "mode0-field"])
+@pytest.fixture(scope="module", params=[(1, 0, 1), (1, 1, 1), (0, 0, 1), (1, 0, 0)],
+                ids=["mode1", "mode1-fused", "mode0-field", "mode1-d2h-copy"])
 def ctx(request):
-    """Every kernel pipeline: mode 1 = score-only sweep + checkpointed replay (default; fused into one launch or as
-    two launches), mode 0 = direction field in HBM."""
+    """Every kernel pipeline: mode 1 = score-only sweep + checkpointed replay (default; as two launches or fused
+    into one), mode 0 = direction field in HBM; results written straight to pinned host memory or fetched by a copy."""
     c = sw.Context(0)
     c.set_option("mode", request.param[0])
     c.set_option("fuse", request.param[1])
+    c.set_option("zero_copy", request.param[2])
     yield c
     c.close()
 
