@@ -538,16 +538,15 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
             fu.f = fa; fu.t = ta;
             if (ctx->profiling) HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
             HIP_TRY(swmi_launch_fused(&fu, ctx->stream));
-            if (ctx->profiling) { HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream)); HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream)); HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream)); }
+            if (ctx->profiling) { HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream)); HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream)); }
             rs.launches++;
         } else {
             if (attempt == 0) {       // the workspace survives an arena-overflow retry
                 if (ctx->profiling) HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
                 HIP_TRY(swmi_launch_fill(&fa, ctx->stream));
-                if (ctx->profiling) HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
                 rs.launches++;
             }
-            if (ctx->profiling) HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
+            if (ctx->profiling) HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));     // end of the sweep = start of the traceback
             HIP_TRY(swmi_launch_traceback(&ta, ctx->stream));
             if (ctx->profiling) HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
         }
@@ -559,8 +558,8 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
         if (!zc) {
             if ((rc = b->h_result.reserve(a_off + arena_cap * 4))) return rc;
             HIP_TRY(hipMemcpyAsync(b->h_result.p, res, copy_bytes, hipMemcpyDeviceToHost, ctx->stream));
+            if (ctx->profiling) HIP_TRY(hipEventRecord(ctx->ev[4], ctx->stream));
         }
-        if (ctx->profiling) HIP_TRY(hipEventRecord(ctx->ev[4], ctx->stream));
         const auto c1 = std::chrono::steady_clock::now();
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         const auto c2 = std::chrono::steady_clock::now();
@@ -569,8 +568,8 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
         if (ctx->profiling) {
             float ms = 0;
             if (attempt == 0) { HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1])); rs.fill_ms += ms; }
-            HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3])); rs.tb_ms += ms;
-            HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4])); rs.d2h_ms += ms;
+            HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[3])); rs.tb_ms += ms;
+            if (!zc) { HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4])); rs.d2h_ms += ms; }
         }
         if (ta.dbg) {
             std::vector<unsigned long long> d(np * 4);

@@ -755,12 +755,17 @@ __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDes
     }
 }
 
+// 4 wavefronts per workgroup (one pair each, like the sweep) so that the walks of slot 0 -- one per pair -- land
+// one per SIMD; the extra slots' few walks fall where they may.
 template <int TMODE>
-__device__ __forceinline__ void traceback_entry(const TraceArgs &A, uint32_t *tb_lds) {
-    const uint32_t pair = blockIdx.x;
+__device__ __forceinline__ void traceback_entry(const TraceArgs &A, uint32_t *lds_all) {
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t pair = blockIdx.x * FILL_WAVES + wave;
     if (pair >= A.n_pairs) return;
-    const uint32_t lane = threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
     const uint32_t slot = blockIdx.y;
+    uint32_t *tb_lds = lds_all + wave * (A.lds_words + A.lds_read_words + SWMI_TB_REFWIN_WORDS +
+                                         (TMODE == 0 ? SWMI_TB_BLOCKS : SWMI_CK_BLOCKS) * SWMI_RMAX * WAVE);
     const PairDesc pd = A.pairs[pair];
     const PairOut po = A.out[pd.out_id];
     if (A.out_host && slot == 0 && lane == 0) A.out_host[pd.out_id] = po;      // result straight into pinned host memory
@@ -801,13 +806,13 @@ sw_align_fused_kernel(const FusedArgs A) {
     else             traceback_pair<4, 1>(A.t, pd, po, lane, 0u, 1u, lds);
 }
 
-extern "C" __global__ void __launch_bounds__(WAVE)
+extern "C" __global__ void __launch_bounds__(WAVE * FILL_WAVES)
 sw_traceback_kernel(const TraceArgs A) {
     extern __shared__ uint32_t tb_lds[];
     traceback_entry<0>(A, tb_lds);
 }
 
-extern "C" __global__ void __launch_bounds__(WAVE)
+extern "C" __global__ void __launch_bounds__(WAVE * FILL_WAVES)
 sw_traceback_replay_kernel(const TraceArgs A) {
     extern __shared__ uint32_t tb_lds[];
     traceback_entry<1>(A, tb_lds);
@@ -835,8 +840,8 @@ extern "C" hipError_t swmi_launch_fused(const FusedArgs *a, hipStream_t st) {
 extern "C" hipError_t swmi_launch_traceback(const TraceArgs *a, hipStream_t st) {
     if (a->n_pairs == 0) return hipSuccess;
     const size_t tile = (size_t)(a->mode == 0 ? SWMI_TB_BLOCKS : SWMI_CK_BLOCKS) * SWMI_RMAX * WAVE;
-    const size_t lds = ((size_t)a->lds_words + a->lds_read_words + SWMI_TB_REFWIN_WORDS + tile) * sizeof(uint32_t);
-    const dim3 grid(a->n_pairs, SWMI_TB_SLOTS), block(WAVE);
+    const size_t lds = ((size_t)a->lds_words + a->lds_read_words + SWMI_TB_REFWIN_WORDS + tile) * sizeof(uint32_t) * FILL_WAVES;
+    const dim3 grid((a->n_pairs + FILL_WAVES - 1) / FILL_WAVES, SWMI_TB_SLOTS), block(WAVE * FILL_WAVES);
     if (a->mode == 0) hipLaunchKernelGGL(sw_traceback_kernel, grid, block, lds, st, *a);
     else              hipLaunchKernelGGL(sw_traceback_replay_kernel, grid, block, lds, st, *a);
     return hipGetLastError();
