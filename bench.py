@@ -36,8 +36,7 @@ def main():
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--d2h-copy", action="store_true", help="fetch results with a D2H copy instead of zero-copy writes to pinned memory")
-    ap.add_argument("--fuse", action="store_true", help="mode 1 as ONE launch (sweep + replay + walk per wavefront)")
-    ap.add_argument("--mode", type=int, default=None, help="kernel pipeline: 1 = score-only sweep + replay (default), 0 = HBM direction field")
+    ap.add_argument("--mode", type=int, default=None, help="kernel pipeline (include/swmi.h): 1 default, 2 event-tracked maxima, 0 HBM direction field")
     args = ap.parse_args()
 
     import torch
@@ -79,12 +78,10 @@ def main():
     ctx.set_option("profiling", 1)
     if args.mode is not None:
         ctx.set_option("mode", args.mode)
-    if args.fuse:
-        ctx.set_option("fuse", 1)
     if args.d2h_copy:
         ctx.set_option("zero_copy", 0)
     mode = 1 if args.mode is None else args.mode
-    kernel_name = "sw_fill_kernel" if mode == 0 else ("sw_align_fused_kernel" if args.fuse else "sw_fill_score_kernel")
+    kernel_name = {0: "sw_fill_kernel", 1: "sw_sweep_winmax_kernel", 2: "sw_fill_score_kernel"}[mode]
     batch = ctx.upload(refs, reads)          # H2D happens here, outside the timed region
     params = sw.make_params()
 

@@ -78,11 +78,16 @@ void        swmi_default_params(swmi_params *p);
 /* Tuning knobs (all optional).  cell_cap: tied-maximum cells kept per pair in the
  * fast path (pairs with more are re-run on the GPU with an exact-size list);
  * max_workspace_bytes: cap on the per-batch workspace arena (larger batches are run in
- * chunks); profiling != 0 brackets every kernel with HIP events; mode: 1 (default) = the
- * fill sweeps scores only and leaves lane-state checkpoints, the traceback re-sweeps the
- * 64-step windows a path crosses with direction bits into LDS; 0 = the fill writes the whole
- * 2-bit direction field to HBM and the traceback reads it (cheaper when most pairs have many
- * tied maxima).  Results are identical in both modes. */
+ * chunks); profiling != 0 brackets every kernel with HIP events; zero_copy (default 1): kernels
+ * write results straight into pinned host memory instead of a D2H copy; mode selects the kernel
+ * pipeline -- results are identical in all of them:
+ *   1 (default)  the sweep computes scores only, leaves lane-state checkpoints and ONE maximum per
+ *                32-step window; the traceback re-sweeps the windows holding the pair's maximum to list
+ *                its cells, and the windows each alignment path crosses to get direction bits (into LDS).
+ *                Needs mismatch <= 0 and gap <= 0; other scores run as mode 2.
+ *   2            as 1, but tied maxima are tracked during the sweep (per-step test + rare handler).
+ *   0            the sweep writes the whole 2-bit direction field to HBM and the traceback reads it
+ *                (cheaper when most pairs have many tied maxima). */
 int         swmi_set_option(swmi_ctx *ctx, const char *name, int64_t value);
 
 /* ---- staged path: upload once, run many times (what bench.py times) ------------- */

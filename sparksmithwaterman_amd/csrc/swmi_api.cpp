@@ -25,7 +25,6 @@
 
 extern "C" hipError_t swmi_launch_fill(const FillArgs *a, hipStream_t st);
 extern "C" hipError_t swmi_launch_traceback(const TraceArgs *a, hipStream_t st);
-extern "C" hipError_t swmi_launch_fused(const FusedArgs *a, hipStream_t st);
 
 // ------------------------------------------------------------------------------------------
 // errors
@@ -98,10 +97,8 @@ struct swmi_ctx {
     uint32_t cell_cap = 64;
     uint64_t max_workspace_bytes = 32ull << 30;
     int profiling = 0;
-    uint32_t mode = 1;                      // 0 = direction field in HBM, 1 = score-only sweep + checkpointed replay
+    uint32_t mode = 1;                      // requested pipeline (see swmi.h); mode 1 falls back to 2 for scores it cannot handle
     int zero_copy = 1;                      // kernels write results straight into pinned host memory (no D2H copy)
-    int fuse = 0;                           // mode 1: sweep and walk in one launch (off: measured slower whenever some pairs
-                                            // have several tied maxima, because their walks then serialise on one wavefront)
     uint64_t arena_words_per_pair = 48;     // first guess of the record arena, grows on demand
     uint64_t arena_copy_wpp = 48;           // arena words per pair fetched with the first D2H (tracks the last run)
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -147,6 +144,7 @@ struct swmi_batch {
     bool has_run = false;
     std::vector<Work> work;                 // schedule (pairs sorted by work), valid for work_mode
     int work_mode = -1;
+    uint32_t eff_mode = 1;                  // pipeline of the current run
     uint64_t work_cells = 0;
     std::vector<uint8_t> pairs_on_device;   // image of the PairDesc array currently in d_pairs
     const void *pairs_dev_ptr = nullptr;
@@ -231,12 +229,10 @@ extern "C" int swmi_set_option(swmi_ctx *ctx, const char *name, int64_t value) {
         if (value < (1 << 20)) return fail(SWMI_ERR_INVALID, "max_workspace_bytes too small");
         ctx->max_workspace_bytes = (uint64_t)value;
     } else if (!strcmp(name, "mode")) {
-        if (value != 0 && value != 1) return fail(SWMI_ERR_INVALID, "mode must be 0 or 1");
+        if (value < 0 || value > 2) return fail(SWMI_ERR_INVALID, "mode must be 0, 1 or 2");
         ctx->mode = (uint32_t)value;
     } else if (!strcmp(name, "zero_copy")) {
         ctx->zero_copy = value != 0;
-    } else if (!strcmp(name, "fuse")) {
-        ctx->fuse = value != 0;
     } else if (!strcmp(name, "profiling")) {
         ctx->profiling = value != 0;
     } else if (!strcmp(name, "arena_words_per_pair")) {
@@ -492,7 +488,7 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
         fa.cell_cap = ctx->cell_cap;
         fa.match = b->params.match; fa.mismatch = b->params.mismatch; fa.gap = b->params.gap;
         fa.strict = b->params.tie_mode == SWMI_TIE_STRICT;
-        fa.mode = ctx->mode;
+        fa.mode = b->eff_mode;
         fa.pad2 = 0;
 
         TraceArgs &ta = rs.ta;
@@ -506,7 +502,7 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
         ta.match = fa.match; ta.mismatch = fa.mismatch; ta.gap = fa.gap; ta.strict = fa.strict;
         ta.lds_words = lds_words;
         ta.seam = fa.seam;
-        ta.mode = ctx->mode;
+        ta.mode = b->eff_mode;
         ta.pad2 = 0;
         ta.lds_read_words = lds_read_words;
         ta.out_host = nullptr;
@@ -528,28 +524,14 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
             ta.dbg = b->d_dbg2.as<unsigned long long>();
         }
 
-        const bool fused = ctx->mode == 1 && ctx->fuse && attempt == 0;
-        if (fused) {
-            // one launch: sweep + walk per wavefront.  The arena header is zeroed by a memset node ahead of it
-            // (waves start appending at different times, so no wave of the launch can do it).
-            fa.hdr = nullptr;
-            HIP_TRY(hipMemsetAsync(res, 0, 64, ctx->stream));
-            FusedArgs fu;
-            fu.f = fa; fu.t = ta;
+        if (attempt == 0) {       // the workspace survives an arena-overflow retry
             if (ctx->profiling) HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
-            HIP_TRY(swmi_launch_fused(&fu, ctx->stream));
-            if (ctx->profiling) { HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream)); HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream)); }
+            HIP_TRY(swmi_launch_fill(&fa, ctx->stream));
             rs.launches++;
-        } else {
-            if (attempt == 0) {       // the workspace survives an arena-overflow retry
-                if (ctx->profiling) HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
-                HIP_TRY(swmi_launch_fill(&fa, ctx->stream));
-                rs.launches++;
-            }
-            if (ctx->profiling) HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));     // end of the sweep = start of the traceback
-            HIP_TRY(swmi_launch_traceback(&ta, ctx->stream));
-            if (ctx->profiling) HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
         }
+        if (ctx->profiling) HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));     // end of the sweep = start of the traceback
+        HIP_TRY(swmi_launch_traceback(&ta, ctx->stream));
+        if (ctx->profiling) HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
 
         // without zero-copy: one D2H of header + pair outputs + as much of the arena as the previous run used
         // (plus slack); the rare remainder is fetched after the header has been read
@@ -699,7 +681,9 @@ extern "C" int swmi_batch_run(swmi_ctx *ctx, swmi_batch *b, const swmi_params *p
 
     // pairs with an empty side never enter ScoreMatrix's loops (SmithWaterman.java:157-159): (0, [])
     // The schedule only depends on the sequence lengths and the pipeline mode: built once per batch.
-    if (b->work_mode != (int)ctx->mode) {
+    // mode 1 needs pad rows that cannot outgrow the real cells they derive from: mismatch <= 0 and gap <= 0
+    b->eff_mode = (ctx->mode == 1 && (p->mismatch > 0 || p->gap > 0)) ? 2u : ctx->mode;
+    if (b->work_mode != (int)b->eff_mode) {
         b->work.clear();
         b->work.reserve(n_pairs);
         b->work_cells = 0;
@@ -711,7 +695,7 @@ extern "C" int swmi_batch_run(swmi_ctx *ctx, swmi_batch *b, const swmi_params *p
                 Work w;
                 w.pair = r * n_reads + q;
                 w.cells = (uint64_t)m * n;
-                w.dir_words = swmi_dir_words(m, n, ctx->mode);
+                w.dir_words = swmi_dir_words(m, n, b->eff_mode);
                 w.seam_words = swmi_seam_words(m, n);
                 b->work_cells += w.cells;
                 b->work.push_back(w);
@@ -719,7 +703,7 @@ extern "C" int swmi_batch_run(swmi_ctx *ctx, swmi_batch *b, const swmi_params *p
         }
         // longest first: the tail of the launch is made of short pairs
         std::stable_sort(b->work.begin(), b->work.end(), [](const Work &a, const Work &c) { return a.cells > c.cells; });
-        b->work_mode = (int)ctx->mode;
+        b->work_mode = (int)b->eff_mode;
     }
     const std::vector<Work> &work = b->work;
     const uint64_t total_cells = b->work_cells;

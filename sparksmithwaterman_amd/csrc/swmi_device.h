@@ -99,7 +99,7 @@ struct FillArgs {
     uint32_t        cell_cap;
     int32_t         match, mismatch, gap;
     uint32_t        strict;      // tie mode
-    uint32_t        mode;        // 0 = direction field in HBM, 1 = score-only sweep + checkpoints
+    uint32_t        mode;        // 0 = direction field in HBM, 1 = checkpoints + window maxima, 2 = checkpoints + event-tracked maxima
     uint32_t        pad2;
 };
 
@@ -126,24 +126,24 @@ struct TraceArgs {
     const int32_t  *seam;        // mode 1: strip seam rows for the replay of multi-strip pairs
     PairOut        *out_host;    // zero-copy results: host-mapped mirror of out[] (written by slot 0 of every pair), or null
     uint32_t       *ovf_host;    // zero-copy results: set to 1 when a record did not fit the (host-mapped) arena
-    uint32_t        mode;        // 0 = read the HBM direction field, 1 = replay windows from checkpoints
+    uint32_t        mode;        // same as FillArgs.mode
     uint32_t        pad2;
 };
-
-struct FusedArgs { FillArgs f; TraceArgs t; };
 
 // rows per lane for a read of m bases
 SWMI_HD static inline uint32_t swmi_rows_per_lane(uint32_t m) {
     uint32_t r = (m + 63u) / 64u;
     return r < 1u ? 1u : (r > SWMI_RMAX ? SWMI_RMAX : r);
 }
-// dwords of per-pair workspace: the direction field (mode 0) or the lane-state checkpoints (mode 1)
+// dwords of per-pair workspace.  mode 0: the direction field; mode 1: lane-state checkpoints + one maximum per
+// checkpoint window; mode 2: lane-state checkpoints.
 SWMI_HD static inline uint64_t swmi_dir_words(uint32_t m, uint32_t n, uint32_t mode) {
     uint32_t R = swmi_rows_per_lane(m);
     uint64_t strips = ((uint64_t)m + 64u * R - 1u) / (64u * R);
     uint64_t wblocks = ((uint64_t)n + 63u + 15u) / 16u;   // T = n + 63 steps at most
     if (mode == 0) return strips * wblocks * R * 64u;
-    return strips * ((wblocks + SWMI_CK_BLOCKS - 1u) / SWMI_CK_BLOCKS) * (R + 2u) * 64u;
+    uint64_t n_ck = (wblocks + SWMI_CK_BLOCKS - 1u) / SWMI_CK_BLOCKS;
+    return strips * (n_ck * (R + 2u) * 64u + (mode == 1 ? ((n_ck + 63u) & ~(uint64_t)63u) : 0u));
 }
 // int32 seam rows of a pair whose read spans several strips: one row of n+1 per strip
 SWMI_HD static inline uint64_t swmi_seam_words(uint32_t m, uint32_t n) {

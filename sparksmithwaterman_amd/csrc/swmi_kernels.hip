@@ -114,12 +114,17 @@ template <int R, bool ACGT, bool STRICT, bool DIRS> using Cells = CellsAsm<R, AC
 #endif
 
 // What a 16-step block does besides the scores:
-//   SWMI_MODE_FIELD   fill, direction bits packed and stored to HBM, tied maxima tracked          (mode 0 fill kernel)
-//   SWMI_MODE_SCORE   fill, scores only (5 VALU per cell) + lane-state checkpoints, maxima tracked (mode 1 fill kernel)
-//   SWMI_MODE_REPLAY  a checkpoint-to-checkpoint window re-swept, direction bits to LDS, nothing tracked (mode 1 traceback)
+//   SWMI_MODE_FIELD   sweep, direction bits packed and stored to HBM, tied maxima tracked by events          (mode 0 sweep)
+//   SWMI_MODE_SCORE   sweep, scores only (5 VALU per cell) + checkpoints, tied maxima tracked by events      (mode 2 sweep)
+//   SWMI_MODE_REPLAY  a checkpoint-to-checkpoint window re-swept, direction bits to LDS, nothing tracked     (mode 1/2 traceback)
+//   SWMI_MODE_WINMAX  sweep, scores only + checkpoints; per lane only a running maximum (no compare, no branch,
+//                     no cell list): the wave reduces it to ONE maximum per checkpoint window                 (mode 1 sweep)
+//   SWMI_MODE_DETECT  a window re-swept like REPLAY that also lists its cells equal to the pair's maximum     (mode 1 traceback)
 #define SWMI_MODE_FIELD  0
 #define SWMI_MODE_SCORE  1
 #define SWMI_MODE_REPLAY 2
+#define SWMI_MODE_WINMAX 3
+#define SWMI_MODE_DETECT 4
 
 // ------------------------------------------------------------------------------------------------
 // rare path: at step t some lane reached the running maximum.  thr / cnt are wave-uniform; they travel
@@ -173,6 +178,7 @@ struct FillState {
     int thr;             // wave-uniform running maximum
     uint32_t cnt;        // wave-uniform number of cells equal to thr
     uint64_t ev_prev;    // lanes whose previous step reached thr (handled one step late, see below)
+    int lmax;            // WINMAX: this lane's maximum H since the last checkpoint
     uint32_t events;     // slow-path entries (diagnostics only)
     bool dbg_skip;       // diagnostics only
 };
@@ -233,8 +239,11 @@ __device__ __forceinline__ void fill_block16(FillState<R> &S, const uint4 w, con
                                              const int seamv, const bool reads_seam, const bool feeds_seam,
                                              int32_t *__restrict__ seam_out,
                                              uint2 *__restrict__ cells, const uint32_t ccap) {
-    constexpr bool DIRS = MODE != SWMI_MODE_SCORE;
-    constexpr bool TRACK = MODE != SWMI_MODE_REPLAY;
+    constexpr bool DIRS = MODE == SWMI_MODE_FIELD || MODE == SWMI_MODE_REPLAY || MODE == SWMI_MODE_DETECT;
+    constexpr bool TRACK = MODE == SWMI_MODE_FIELD || MODE == SWMI_MODE_SCORE;     // deferred tied-maximum events
+    constexpr bool LMAX = MODE == SWMI_MODE_WINMAX;                                  // per-lane running maximum only
+    constexpr bool DETECT = MODE == SWMI_MODE_DETECT;                                // list the cells equal to S.thr
+    constexpr bool FEEDS = MODE == SWMI_MODE_FIELD || MODE == SWMI_MODE_SCORE || MODE == SWMI_MODE_WINMAX;   // sweep (writes seam rows)
     using C = Cells<R, ACGT, DIRS ? STRICT : false, DIRS>;
 #pragma unroll
     for (uint32_t s = 0; s < 16; ++s) {
@@ -256,26 +265,51 @@ __device__ __forceinline__ void fill_block16(FillState<R> &S, const uint4 w, con
             const uint32_t c0 = t0 + s - lane_eff;                         // column index j-1 of this lane
             if (c0 < n) {
                 C::step(hin, hout, S.acc, S.q, S.rb, S.nprev, nin, gap, vmat, vmis);
-                if (TRACK) {
+                if (TRACK || DETECT) {
                     mrow = hout[0];
 #pragma unroll
                     for (int k = 1; k < R; ++k) mrow = mrow > hout[k] ? mrow : hout[k];
                 }
-                if (MULTI && TRACK && feeds_seam && lane == WAVE - 1) seam_out[c0 + 1] = hout[R - 1];
+                if (LMAX) {
+#pragma unroll
+                    for (int k = 0; k < R; ++k) S.lmax = S.lmax > hout[k] ? S.lmax : hout[k];
+                }
+                if (MULTI && FEEDS && feeds_seam && lane == WAVE - 1) seam_out[c0 + 1] = hout[R - 1];
             } else {
 #pragma unroll
                 for (int k = 0; k < R; ++k) hout[k] = hin[k];             // a lane off its range keeps its state
             }
         } else {
             C::step(hin, hout, S.acc, S.q, S.rb, S.nprev, nin, gap, vmat, vmis);
-            if (TRACK) {
+            if (TRACK || DETECT) {
                 mrow = hout[0];
 #pragma unroll
                 for (int k = 1; k < R; ++k) mrow = mrow > hout[k] ? mrow : hout[k];
             }
-            if (MULTI && TRACK && feeds_seam && lane == WAVE - 1) seam_out[t0 + s - lane + 1] = hout[R - 1];
+            if (LMAX) {
+#pragma unroll
+                for (int k = 0; k < R; ++k) S.lmax = S.lmax > hout[k] ? S.lmax : hout[k];
+            }
+            if (MULTI && FEEDS && feeds_seam && lane == WAVE - 1) seam_out[t0 + s - lane + 1] = hout[R - 1];
         }
         S.nprev = nin;
+        if (DETECT) {
+            // replay of a window that holds the pair's maximum: list its cells equal to it (immediate branch: 32 steps only)
+            if (BALLOT(mrow >= S.thr) != 0) {
+                const uint32_t c0d = t0 + s - lane_eff;
+                const bool act = c0d < n;
+#pragma unroll
+                for (int k = 0; k < R; ++k) {
+                    const bool hit = act && (row0 + k < m) && (hout[k] == S.thr);      // SmithWaterman.java:182-185
+                    const uint64_t hm = BALLOT(hit);
+                    if (hm) {
+                        const uint32_t pos = S.cnt + lanemask_lt_count(hm);
+                        if (hit && pos < ccap) cells[pos] = make_uint2(row0 + k + 1, c0d + 1u);
+                        S.cnt += (uint32_t)__popcll(hm);
+                    }
+                }
+            }
+        }
         if (TRACK) {
             const uint64_t ev = BALLOT(mrow >= S.thr);      // all 64 lanes vote: thr / cnt stay wave-uniform
             if (__builtin_expect(S.ev_prev != 0, 0))                           // step t0+s-1, values still in hin
@@ -288,16 +322,20 @@ __device__ __forceinline__ void fill_block16(FillState<R> &S, const uint4 w, con
 // geometry shared by the sweep and its replay
 struct StripGeom {
     uint32_t rps, n_strips, wblocks, n_ck;
-    uint64_t strip_words;        // dwords of workspace per strip (direction field or checkpoints)
+    uint64_t strip_words;        // dwords of workspace per strip
+    uint64_t wmax_off;           // mode 1: offset of the strip's per-window maxima inside its workspace
 };
+// hmode = the pipeline the host selected: 0 direction field, 1 checkpoints + window maxima, 2 checkpoints only
 template <int R>
-__device__ __forceinline__ StripGeom strip_geom(uint32_t m, uint32_t n, uint32_t mode) {
+__device__ __forceinline__ StripGeom strip_geom(uint32_t m, uint32_t n, uint32_t hmode) {
     StripGeom g;
     g.rps = WAVE * R;
     g.n_strips = (m + g.rps - 1) / g.rps;
     g.wblocks = (n + 63u + 15u) / 16u;                       // 16-step blocks reserved per strip
     g.n_ck = (g.wblocks + SWMI_CK_BLOCKS - 1u) / SWMI_CK_BLOCKS;
-    g.strip_words = mode == 0 ? (uint64_t)g.wblocks * R * WAVE : (uint64_t)g.n_ck * (R + 2) * WAVE;
+    g.wmax_off = (uint64_t)g.n_ck * (R + 2) * WAVE;
+    g.strip_words = hmode == 0 ? (uint64_t)g.wblocks * R * WAVE
+                               : g.wmax_off + (hmode == 1 ? (uint64_t)((g.n_ck + 63u) & ~63u) : 0u);
     return g;
 }
 
@@ -314,7 +352,9 @@ __device__ __forceinline__ void fill_pair(const FillArgs &A, const PairDesc pd, 
     const uint32_t *__restrict__ refw = A.seqw + rd.boff;
     const uint32_t *__restrict__ readw = A.seqw + qd.boff;
     const int match = A.match, mismatch = A.mismatch, gap = A.gap;
-    const StripGeom G = strip_geom<R>(m, n, MODE == SWMI_MODE_FIELD ? 0u : 1u);
+    constexpr uint32_t HMODE = MODE == SWMI_MODE_FIELD ? 0u : (MODE == SWMI_MODE_WINMAX ? 1u : 2u);
+    const StripGeom G = strip_geom<R>(m, n, HMODE);
+    int pair_max = 0;        // WINMAX: maximum over the finished windows
 
     const uint64_t cbase = A.cells_off ? A.cells_off[pd.out_id] : (uint64_t)pd.out_id * A.cell_cap;
     const uint32_t ccap = A.cells_cap ? A.cells_cap[pd.out_id] : A.cell_cap;
@@ -335,8 +375,18 @@ __device__ __forceinline__ void fill_pair(const FillArgs &A, const PairDesc pd, 
         const uint32_t T = n + lact - 1;                 // steps of this strip
         const uint32_t lane_eff = lane < lact ? lane : 0x40000000u;   // lanes without rows are never in range
         setup_rows<R, ACGT>(S, readw, row0, m, match, mismatch);
+        S.lmax = -1;
 
         uint32_t *__restrict__ wsp = A.dir + pd.dir_off + s * G.strip_words + lane;   // this strip's workspace
+        // WINMAX: one maximum per checkpoint window.  Lanes without rows are left out; the pad rows of the last lane with
+        // rows cannot exceed the real cells they derive from (mismatch <= 0 and gap <= 0 are required for this mode), so the
+        // pair's maximum is exact and a window can at worst be listed without holding a maximum cell.
+        auto close_window = [&](uint32_t g) {
+            const int wm = wave_max_i32(lane < lact ? S.lmax : -1);
+            if (lane == 0) A.dir[pd.dir_off + s * G.strip_words + G.wmax_off + g] = (uint32_t)wm;
+            pair_max = pair_max > wm ? pair_max : wm;
+            S.lmax = -1;
+        };
         const int32_t *seam_in = nullptr;
         int32_t *seam_out = nullptr;
         if (MULTI) {
@@ -354,7 +404,8 @@ __device__ __forceinline__ void fill_pair(const FillArgs &A, const PairDesc pd, 
             const uint4 w = wnext;                       // base codes of columns 16tb+1 .. 16tb+16
             wnext = refq[tb + 1];                        // prefetch (images are padded)
             const uint32_t t0 = 16u * tb;
-            if (MODE == SWMI_MODE_SCORE && (tb % SWMI_CK_BLOCKS) == 0u) {
+            if (MODE == SWMI_MODE_WINMAX && (tb % SWMI_CK_BLOCKS) == 0u && tb > 0u) close_window(tb / SWMI_CK_BLOCKS - 1u);
+            if ((MODE == SWMI_MODE_SCORE || MODE == SWMI_MODE_WINMAX) && (tb % SWMI_CK_BLOCKS) == 0u) {
                 // checkpoint: everything a replay of steps t0.. needs from this lane ([ck][slot][lane], 256 B stores)
                 uint32_t *__restrict__ ck = wsp + (uint64_t)(tb / SWMI_CK_BLOCKS) * (R + 2) * WAVE;
 #pragma unroll
@@ -388,6 +439,7 @@ __device__ __forceinline__ void fill_pair(const FillArgs &A, const PairDesc pd, 
                 }
             }
         }
+        if (MODE == SWMI_MODE_WINMAX) close_window((nblk - 1u) / SWMI_CK_BLOCKS);
         // the tied-maximum test of the strip's last step is still pending (16 steps per block: its H is in S.h)
         if (S.ev_prev != 0) {
             handle_pending<R>(S, S.h, 16u * nblk - 1u, lane_eff, n, row0, m, cells, ccap);
@@ -398,7 +450,11 @@ __device__ __forceinline__ void fill_pair(const FillArgs &A, const PairDesc pd, 
 
     if (lane == 0) {
         PairOut o;
-        if (S.cnt == 0) { o.score = 0; o.flags = SWMI_F_DEGENERATE; o.n_cells = (uint64_t)m * n; }
+        if (MODE == SWMI_MODE_WINMAX) {
+            // the cells holding the maximum are listed by the traceback kernel (n_cells follows there)
+            if (pair_max <= 0) { o.score = 0; o.flags = SWMI_F_DEGENERATE; o.n_cells = (uint64_t)m * n; }
+            else               { o.score = pair_max; o.flags = 0u; o.n_cells = 0; }
+        } else if (S.cnt == 0) { o.score = 0; o.flags = SWMI_F_DEGENERATE; o.n_cells = (uint64_t)m * n; }
         else            { o.score = S.thr; o.flags = S.cnt > ccap ? SWMI_F_CELL_OVF : 0u; o.n_cells = S.cnt; }
         A.out[pd.out_id] = o;
         if (A.dbg) {
@@ -433,7 +489,7 @@ __device__ __forceinline__ void fill_entry(const FillArgs &A) {
     // profile lookup needs both sequences pure ACGT and scores that fit a signed byte
     const bool acgt = rd.acgt && qd.acgt &&
                       A.match >= -128 && A.match <= 127 && A.mismatch >= -128 && A.mismatch <= 127;
-    if (MODE == SWMI_MODE_SCORE) {                     // scores do not depend on the tie order
+    if (MODE == SWMI_MODE_SCORE || MODE == SWMI_MODE_WINMAX) {   // scores do not depend on the tie order
         if (acgt) fill_dispatch<true, false, MODE>(A, pd, lane, qd.len);
         else      fill_dispatch<false, false, MODE>(A, pd, lane, qd.len);
     } else if (acgt) {
@@ -450,6 +506,9 @@ sw_fill_kernel(const FillArgs A) { fill_entry<SWMI_MODE_FIELD>(A); }
 
 extern "C" __global__ void __launch_bounds__(WAVE * FILL_WAVES)
 sw_fill_score_kernel(const FillArgs A) { fill_entry<SWMI_MODE_SCORE>(A); }
+
+extern "C" __global__ void __launch_bounds__(WAVE * FILL_WAVES)
+sw_sweep_winmax_kernel(const FillArgs A) { fill_entry<SWMI_MODE_WINMAX>(A); }
 
 // ------------------------------------------------------------------------------------------------
 // traceback: SWMI_TB_SLOTS wavefronts per pair (slot x walks the tied cells x, x+SLOTS, ...).
@@ -471,14 +530,17 @@ sw_fill_score_kernel(const FillArgs A) { fill_entry<SWMI_MODE_SCORE>(A); }
 #define SWMI_TB_REFWIN_WORDS 96u      // (16*16 + 63) / 4 + slack
 #define SWMI_TB_SLOTS 4u
 
-// mode 1: re-sweep the window of SWMI_CK_BLOCKS blocks that starts at block `wlo` of strip `s` into lds_tile
-template <int R, bool ACGT, bool STRICT, bool MULTI>
-__device__ __forceinline__ void replay_window(const TraceArgs &A, const PairDesc pd, const uint32_t n, const uint32_t m,
-                                              const uint32_t *__restrict__ refw, const uint32_t *__restrict__ readw,
-                                              const StripGeom G, const uint32_t s, const uint32_t wlo,
-                                              const uint32_t lane, uint32_t *__restrict__ lds_tile) {
+// re-sweep the window of SWMI_CK_BLOCKS blocks that starts at block `wlo` of strip `s` into lds_tile.
+// DETECT: also append the window's cells equal to `maxv` to the pair's cell list; returns the new list length.
+template <int R, bool ACGT, bool STRICT, bool MULTI, bool DETECT>
+__device__ __forceinline__ uint32_t replay_window(const TraceArgs &A, const PairDesc pd, const uint32_t n, const uint32_t m,
+                                                  const uint32_t *__restrict__ refw, const uint32_t *__restrict__ readw,
+                                                  const StripGeom G, const uint32_t s, const uint32_t wlo,
+                                                  const uint32_t lane, uint32_t *__restrict__ lds_tile,
+                                                  const int maxv, const uint32_t cnt_in, uint2 *__restrict__ cells, const uint32_t ccap) {
+    constexpr int BM = DETECT ? SWMI_MODE_DETECT : SWMI_MODE_REPLAY;
     FillState<R> S;
-    S.thr = 0x7FFFFFFF; S.cnt = 0; S.ev_prev = 0; S.events = 0; S.dbg_skip = false;
+    S.thr = DETECT ? maxv : 0x7FFFFFFF; S.cnt = cnt_in; S.ev_prev = 0; S.events = 0; S.dbg_skip = false; S.lmax = -1;
     const uint32_t row0 = s * G.rps + lane * R;
     const uint32_t rows_left = m - s * G.rps;
     const uint32_t lact = rows_left >= G.rps ? WAVE : (rows_left + R - 1) / R;
@@ -512,11 +574,11 @@ __device__ __forceinline__ void replay_window(const TraceArgs &A, const PairDesc
         }
         const bool steady = (t0 + 1u >= lact) && (t0 + 15u < n);
         if (steady)
-            fill_block16<R, ACGT, STRICT, MULTI, false, SWMI_MODE_REPLAY>(S, w, t0, lane, lane_eff, n, m, row0, A.gap, A.match, A.mismatch,
-                                                                          seamv, reads_seam, false, nullptr, nullptr, 0u);
+            fill_block16<R, ACGT, STRICT, MULTI, false, BM>(S, w, t0, lane, lane_eff, n, m, row0, A.gap, A.match, A.mismatch,
+                                                            seamv, reads_seam, false, nullptr, cells, ccap);
         else
-            fill_block16<R, ACGT, STRICT, MULTI, true, SWMI_MODE_REPLAY>(S, w, t0, lane, lane_eff, n, m, row0, A.gap, A.match, A.mismatch,
-                                                                         seamv, reads_seam, false, nullptr, nullptr, 0u);
+            fill_block16<R, ACGT, STRICT, MULTI, true, BM>(S, w, t0, lane, lane_eff, n, m, row0, A.gap, A.match, A.mismatch,
+                                                           seamv, reads_seam, false, nullptr, cells, ccap);
         const int miss = (int)(t0 + 15u) - ((int)(lane + n) - 1);
 #pragma unroll
         for (int k = 0; k < R; ++k) {
@@ -525,19 +587,67 @@ __device__ __forceinline__ void replay_window(const TraceArgs &A, const PairDesc
             lds_tile[(b * R + k) * WAVE + lane] = v;
         }
     }
+    return S.cnt;
 }
 
-template <int R, bool MULTI>
-__device__ __forceinline__ void replay_dispatch(const TraceArgs &A, const PairDesc pd, uint32_t n, uint32_t m, bool acgt,
-                                                const uint32_t *__restrict__ refw, const uint32_t *__restrict__ readw,
-                                                const StripGeom G, uint32_t s, uint32_t wlo, uint32_t lane, uint32_t *lds_tile) {
+template <int R, bool MULTI, bool DETECT>
+__device__ __forceinline__ uint32_t replay_dispatch(const TraceArgs &A, const PairDesc pd, uint32_t n, uint32_t m, bool acgt,
+                                                    const uint32_t *__restrict__ refw, const uint32_t *__restrict__ readw,
+                                                    const StripGeom G, uint32_t s, uint32_t wlo, uint32_t lane, uint32_t *lds_tile,
+                                                    int maxv, uint32_t cnt_in, uint2 *__restrict__ cells, uint32_t ccap) {
     if (acgt) {
-        if (A.strict) replay_window<R, true, true, MULTI>(A, pd, n, m, refw, readw, G, s, wlo, lane, lds_tile);
-        else          replay_window<R, true, false, MULTI>(A, pd, n, m, refw, readw, G, s, wlo, lane, lds_tile);
+        if (A.strict) return replay_window<R, true, true, MULTI, DETECT>(A, pd, n, m, refw, readw, G, s, wlo, lane, lds_tile, maxv, cnt_in, cells, ccap);
+        else          return replay_window<R, true, false, MULTI, DETECT>(A, pd, n, m, refw, readw, G, s, wlo, lane, lds_tile, maxv, cnt_in, cells, ccap);
     } else {
-        if (A.strict) replay_window<R, false, true, MULTI>(A, pd, n, m, refw, readw, G, s, wlo, lane, lds_tile);
-        else          replay_window<R, false, false, MULTI>(A, pd, n, m, refw, readw, G, s, wlo, lane, lds_tile);
+        if (A.strict) return replay_window<R, false, true, MULTI, DETECT>(A, pd, n, m, refw, readw, G, s, wlo, lane, lds_tile, maxv, cnt_in, cells, ccap);
+        else          return replay_window<R, false, false, MULTI, DETECT>(A, pd, n, m, refw, readw, G, s, wlo, lane, lds_tile, maxv, cnt_in, cells, ccap);
     }
+}
+
+// replays with or without the multi-strip seam handling (only R == SWMI_RMAX reads can span several strips)
+template <int R, bool DETECT>
+__device__ __forceinline__ uint32_t replay_any(const TraceArgs &A, const PairDesc pd, uint32_t n, uint32_t m, bool acgt,
+                                               const uint32_t *__restrict__ refw, const uint32_t *__restrict__ readw,
+                                               const StripGeom G, uint32_t s, uint32_t wlo, uint32_t lane, uint32_t *lds_tile,
+                                               int maxv, uint32_t cnt_in, uint2 *__restrict__ cells, uint32_t ccap) {
+    if constexpr (R == SWMI_RMAX) {
+        if (m > WAVE * SWMI_RMAX)
+            return replay_dispatch<R, true, DETECT>(A, pd, n, m, acgt, refw, readw, G, s, wlo, lane, lds_tile, maxv, cnt_in, cells, ccap);
+    }
+    return replay_dispatch<R, false, DETECT>(A, pd, n, m, acgt, refw, readw, G, s, wlo, lane, lds_tile, maxv, cnt_in, cells, ccap);
+}
+
+// mode 1: list the pair's maximum cells.  The sweep left one maximum per checkpoint window; every window whose
+// maximum equals the pair's is re-swept once with the cell test switched on.
+template <int R>
+__device__ __forceinline__ uint32_t detect_cells(const TraceArgs &A, const PairDesc pd, const PairOut po,
+                                                 const uint32_t lane, uint32_t *__restrict__ lds_tile) {
+    const SeqDesc rd = A.refs[pd.ref_id];
+    const SeqDesc qd = A.reads[pd.read_id];
+    const uint32_t n = rd.len, m = qd.len;
+    const uint32_t *__restrict__ refw = A.seqw + rd.boff;
+    const uint32_t *__restrict__ readw = A.seqw + qd.boff;
+    const StripGeom G = strip_geom<R>(m, n, 1u);
+    const bool acgt = rd.acgt && qd.acgt && A.match >= -128 && A.match <= 127 && A.mismatch >= -128 && A.mismatch <= 127;
+    const uint64_t cbase = A.cells_off ? A.cells_off[pd.out_id] : (uint64_t)pd.out_id * A.cell_cap;
+    const uint32_t ccap = A.cells_cap ? A.cells_cap[pd.out_id] : A.cell_cap;
+    uint2 *__restrict__ cells = const_cast<uint2 *>(A.cells) + cbase;
+    uint32_t cnt = 0;
+    for (uint32_t s = 0; s < G.n_strips; ++s) {
+        const uint32_t *__restrict__ wm = A.dir + pd.dir_off + s * G.strip_words + G.wmax_off;
+        for (uint32_t g0 = 0; g0 < G.n_ck; g0 += WAVE) {
+            const uint32_t g = g0 + lane;
+            const int wv = g < G.n_ck ? (int)wm[g] : -1;
+            uint64_t cand = BALLOT(wv == po.score);
+            while (cand) {
+                const uint32_t gg = g0 + (uint32_t)__builtin_ctzll(cand);
+                cand &= cand - 1ull;
+                cnt = replay_any<R, true>(A, pd, n, m, acgt, refw, readw, G, s, gg * SWMI_CK_BLOCKS, lane, lds_tile,
+                                          po.score, cnt, cells, ccap);
+            }
+        }
+    }
+    return cnt;
 }
 
 template <int R, int TMODE>
@@ -549,7 +659,7 @@ __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDes
     const uint32_t n = rd.len, m = qd.len;
     const uint32_t *__restrict__ refw = A.seqw + rd.boff;
     const uint32_t *__restrict__ readw = A.seqw + qd.boff;
-    const StripGeom G = strip_geom<R>(m, n, TMODE);
+    const StripGeom G = strip_geom<R>(m, n, A.mode);
     const uint32_t rps = G.rps;
     const uint32_t *__restrict__ dirp = A.dir + pd.dir_off;
     const uint32_t umat = (uint32_t)A.match, umis = (uint32_t)A.mismatch, ugap = (uint32_t)A.gap;
@@ -618,12 +728,7 @@ __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDes
                     const uint32_t *__restrict__ src = dirp + s * G.strip_words + (uint64_t)wlo * R * WAVE + lane;
                     for (uint32_t x = 0; x < nb * R; ++x) lds_tile[x * WAVE + lane] = src[(uint64_t)x * WAVE];
                 } else {
-                    bool multi = false;
-                    if constexpr (R == SWMI_RMAX) multi = m > WAVE * SWMI_RMAX;
-                    if constexpr (R == SWMI_RMAX) {
-                        if (multi) replay_dispatch<R, true>(A, pd, n, m, acgt, refw, readw, G, s, wlo, lane, lds_tile);
-                    }
-                    if (!multi) replay_dispatch<R, false>(A, pd, n, m, acgt, refw, readw, G, s, wlo, lane, lds_tile);
+                    (void)replay_any<R, false>(A, pd, n, m, acgt, refw, readw, G, s, wlo, lane, lds_tile, 0, 0u, nullptr, 0u);
                 }
                 const int clo = (int)(16u * wlo) - 63;
                 const uint32_t cw0 = clo > 0 ? (uint32_t)clo >> 2 : 0u;           // first dword of the reference window
@@ -778,32 +883,49 @@ __device__ __forceinline__ void traceback_entry(const TraceArgs &A, uint32_t *ld
     else             traceback_pair<4, TMODE>(A, pd, po, lane, slot, SWMI_TB_SLOTS, tb_lds);
 }
 
-// mode 1, one launch: every wavefront sweeps its pair (scores + checkpoints) and then walks that pair's
-// alignments itself.  No second launch, no grid-wide wait between the two phases: a pair's traceback starts the
-// moment its own sweep ends, so the launch lasts max(sweep_i + walk_i), not max(sweep) + max(walk).
+// mode 1: one workgroup = the 4 walk slots of ONE pair.  Wave 0 first lists the maximum cells (detect_cells),
+// the workgroup meets at a barrier, then every wave walks its share of the alignments.
 extern "C" __global__ void __launch_bounds__(WAVE * FILL_WAVES)
-sw_align_fused_kernel(const FusedArgs A) {
-    extern __shared__ uint32_t fused_lds[];
-    fill_entry<SWMI_MODE_SCORE>(A.f);
-    const uint32_t wave = threadIdx.x >> 6;
-    const uint32_t pair = blockIdx.x * FILL_WAVES + wave;
-    if (pair >= A.f.n_pairs) return;
-    const uint32_t lane = threadIdx.x & 63u;
-    const PairDesc pd = A.t.pairs[pair];
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's PairOut, cell list and checkpoints have left the CU
-    PairOut po;
-    const uint32_t *op = reinterpret_cast<const uint32_t *>(A.t.out + pd.out_id);
-    po.score = (int32_t)ld_l2(op);
-    po.flags = ld_l2(op + 1);
-    po.n_cells = ((uint64_t)ld_l2(op + 3) << 32) | ld_l2(op + 2);
-    if (A.t.out_host && lane == 0) A.t.out_host[pd.out_id] = po;
-    if (po.flags & (SWMI_F_DEGENERATE | SWMI_F_CELL_OVF)) return;
-    uint32_t *lds = fused_lds + wave * (A.t.lds_words + A.t.lds_read_words + SWMI_TB_REFWIN_WORDS + SWMI_CK_BLOCKS * SWMI_RMAX * WAVE);
-    const uint32_t R = swmi_rows_per_lane(A.t.reads[pd.read_id].len);
-    if (R == 1)      traceback_pair<1, 1>(A.t, pd, po, lane, 0u, 1u, lds);
-    else if (R == 2) traceback_pair<2, 1>(A.t, pd, po, lane, 0u, 1u, lds);
-    else if (R == 3) traceback_pair<3, 1>(A.t, pd, po, lane, 0u, 1u, lds);
-    else             traceback_pair<4, 1>(A.t, pd, po, lane, 0u, 1u, lds);
+sw_traceback_winmax_kernel(const TraceArgs A) {
+    extern __shared__ uint32_t wm_lds[];
+    const uint32_t pair = blockIdx.x;
+    if (pair >= A.n_pairs) return;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const PairDesc pd = A.pairs[pair];
+    PairOut po = A.out[pd.out_id];
+    if (po.flags & SWMI_F_DEGENERATE) {                      // same decision in all 4 waves: nobody waits at the barrier
+        if (A.out_host && wave == 0 && lane == 0) A.out_host[pd.out_id] = po;
+        return;
+    }
+    const uint32_t per_wave = A.lds_words + A.lds_read_words + SWMI_TB_REFWIN_WORDS + SWMI_CK_BLOCKS * SWMI_RMAX * WAVE;
+    uint32_t *shared = wm_lds;                               // [0] = number of maximum cells
+    uint32_t *lds = wm_lds + 4 + wave * per_wave;
+    const uint32_t R = swmi_rows_per_lane(A.reads[pd.read_id].len);
+    const uint32_t ccap = A.cells_cap ? A.cells_cap[pd.out_id] : A.cell_cap;
+    if (wave == 0) {
+        uint32_t *tile = lds + A.lds_words + A.lds_read_words + SWMI_TB_REFWIN_WORDS;
+        uint32_t cnt;
+        if (R == 1)      cnt = detect_cells<1>(A, pd, po, lane, tile);
+        else if (R == 2) cnt = detect_cells<2>(A, pd, po, lane, tile);
+        else if (R == 3) cnt = detect_cells<3>(A, pd, po, lane, tile);
+        else             cnt = detect_cells<4>(A, pd, po, lane, tile);
+        if (lane == 0) {
+            po.n_cells = cnt;
+            if (cnt > ccap) po.flags |= SWMI_F_CELL_OVF;
+            A.out[pd.out_id] = po;
+            if (A.out_host) A.out_host[pd.out_id] = po;
+            shared[0] = cnt;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the cell list has left the CU before the others read it
+    }
+    __syncthreads();
+    const uint32_t cnt = shared[0];
+    if (cnt > ccap || wave >= cnt) return;
+    po.n_cells = cnt;
+    if (R == 1)      traceback_pair<1, 1>(A, pd, po, lane, wave, FILL_WAVES, lds);
+    else if (R == 2) traceback_pair<2, 1>(A, pd, po, lane, wave, FILL_WAVES, lds);
+    else if (R == 3) traceback_pair<3, 1>(A, pd, po, lane, wave, FILL_WAVES, lds);
+    else             traceback_pair<4, 1>(A, pd, po, lane, wave, FILL_WAVES, lds);
 }
 
 extern "C" __global__ void __launch_bounds__(WAVE * FILL_WAVES)
@@ -824,25 +946,23 @@ sw_traceback_replay_kernel(const TraceArgs A) {
 extern "C" hipError_t swmi_launch_fill(const FillArgs *a, hipStream_t st) {
     if (a->n_pairs == 0) return hipSuccess;
     const dim3 grid((a->n_pairs + FILL_WAVES - 1) / FILL_WAVES), block(WAVE * FILL_WAVES);
-    if (a->mode == 0) hipLaunchKernelGGL(sw_fill_kernel, grid, block, 0, st, *a);
-    else              hipLaunchKernelGGL(sw_fill_score_kernel, grid, block, 0, st, *a);
-    return hipGetLastError();
-}
-
-extern "C" hipError_t swmi_launch_fused(const FusedArgs *a, hipStream_t st) {
-    if (a->f.n_pairs == 0) return hipSuccess;
-    const size_t per_wave = (size_t)a->t.lds_words + a->t.lds_read_words + SWMI_TB_REFWIN_WORDS + (size_t)SWMI_CK_BLOCKS * SWMI_RMAX * WAVE;
-    const dim3 grid((a->f.n_pairs + FILL_WAVES - 1) / FILL_WAVES), block(WAVE * FILL_WAVES);
-    hipLaunchKernelGGL(sw_align_fused_kernel, grid, block, per_wave * FILL_WAVES * sizeof(uint32_t), st, *a);
+    if (a->mode == 0)      hipLaunchKernelGGL(sw_fill_kernel, grid, block, 0, st, *a);
+    else if (a->mode == 1) hipLaunchKernelGGL(sw_sweep_winmax_kernel, grid, block, 0, st, *a);
+    else                   hipLaunchKernelGGL(sw_fill_score_kernel, grid, block, 0, st, *a);
     return hipGetLastError();
 }
 
 extern "C" hipError_t swmi_launch_traceback(const TraceArgs *a, hipStream_t st) {
     if (a->n_pairs == 0) return hipSuccess;
     const size_t tile = (size_t)(a->mode == 0 ? SWMI_TB_BLOCKS : SWMI_CK_BLOCKS) * SWMI_RMAX * WAVE;
-    const size_t lds = ((size_t)a->lds_words + a->lds_read_words + SWMI_TB_REFWIN_WORDS + tile) * sizeof(uint32_t) * FILL_WAVES;
-    const dim3 grid((a->n_pairs + FILL_WAVES - 1) / FILL_WAVES, SWMI_TB_SLOTS), block(WAVE * FILL_WAVES);
-    if (a->mode == 0) hipLaunchKernelGGL(sw_traceback_kernel, grid, block, lds, st, *a);
-    else              hipLaunchKernelGGL(sw_traceback_replay_kernel, grid, block, lds, st, *a);
+    const size_t per_wave = (size_t)a->lds_words + a->lds_read_words + SWMI_TB_REFWIN_WORDS + tile;
+    const dim3 block(WAVE * FILL_WAVES);
+    if (a->mode == 1) {
+        hipLaunchKernelGGL(sw_traceback_winmax_kernel, dim3(a->n_pairs), block, (per_wave * FILL_WAVES + 4) * sizeof(uint32_t), st, *a);
+    } else {
+        const dim3 grid((a->n_pairs + FILL_WAVES - 1) / FILL_WAVES, SWMI_TB_SLOTS);
+        if (a->mode == 0) hipLaunchKernelGGL(sw_traceback_kernel, grid, block, per_wave * FILL_WAVES * sizeof(uint32_t), st, *a);
+        else              hipLaunchKernelGGL(sw_traceback_replay_kernel, grid, block, per_wave * FILL_WAVES * sizeof(uint32_t), st, *a);
+    }
     return hipGetLastError();
 }

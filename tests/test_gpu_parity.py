@@ -19,15 +19,14 @@ READ_80 = "AATTTTAGTCTCTCCCTACCCTTTTGGACAGAGCTTCCTGTCCTCTCATTTCACAGGTTATGCAACAGA
 READ_20 = "ACTGACTGACTGACTGACTG"   # EngineerData.java:29
 
 
-@pytest.fixture(scope="module", params=[(1, 0, 1), (1, 1, 1), (0, 0, 1), (1, 0, 0)],
-                ids=["mode1", "mode1-fused", "mode0-field", "mode1-d2h-copy"])
+@pytest.fixture(scope="module", params=[(1, 1), (2, 1), (0, 1), (1, 0)],
+                ids=["mode1-winmax", "mode2-events", "mode0-field", "mode1-d2h-copy"])
 def ctx(request):
-    """Every kernel pipeline: mode 1 = score-only sweep + checkpointed replay (default; as two launches or fused
-    into one), mode 0 = direction field in HBM; results written straight to pinned host memory or fetched by a copy."""
+    """Every kernel pipeline (include/swmi.h, swmi_set_option "mode"), results written straight to pinned host
+    memory or fetched by a copy."""
     c = sw.Context(0)
     c.set_option("mode", request.param[0])
-    c.set_option("fuse", request.param[1])
-    c.set_option("zero_copy", request.param[2])
+    c.set_option("zero_copy", request.param[1])
     yield c
     c.close()
 
