@@ -149,6 +149,11 @@ struct swmi_batch {
     std::vector<uint8_t> pairs_on_device;   // image of the PairDesc array currently in d_pairs
     const void *pairs_dev_ptr = nullptr;
     std::vector<PairRes> pairs;             // by pair index
+    // raw record streams of the last run (one per launch chunk), indexed lazily on the first alignment access
+    struct RawChunk { size_t at, words; size_t lo; std::vector<uint32_t> wpos; };   // wpos: re-run chunks only
+    std::vector<uint32_t> raw;
+    std::vector<RawChunk> raw_chunks;
+    bool indexed = false;
     std::vector<HostAln> alns;              // grouped by pair, ordered as OptAlignments returns them
     std::vector<uint32_t> ops;              // concatenated op words of all records
     std::vector<std::string> str_ref, str_read;   // materialised alignments
@@ -199,6 +204,8 @@ extern "C" int swmi_create(int device, swmi_ctx **out) {
                     device, prop.gcnArchName);
     e = hipSetDevice(device);
     if (e != hipSuccess) return fail(SWMI_ERR_NO_DEVICE, "hipSetDevice: %s", hipGetErrorString(e));
+    (void)hipSetDeviceFlags(hipDeviceScheduleSpin);      // a batch is sub-millisecond: spin on completion (ignored if the device is already active)
+    (void)hipGetLastError();
     std::unique_ptr<swmi_ctx> c(new swmi_ctx);
     c->device = device;
     e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
@@ -627,14 +634,14 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
 // records of one chunk -> per-pair lists (tmp, keyed by position in `work`)
 struct ParsedRec { uint32_t wpos; HostAln a; };
 
-static int parse_records(const std::vector<uint32_t> &arena, uint64_t used, size_t lo,
+static int parse_records(const uint32_t *arena, uint64_t used, size_t lo, const std::vector<uint32_t> *wpos_map,
                          std::vector<uint32_t> &ops, std::vector<ParsedRec> &recs) {
     uint64_t at = 0;
     while (at < used) {
         if (at + SWMI_ALNREC_WORDS > used) return fail(SWMI_ERR_HIP, "truncated record in arena");
-        const uint32_t *w = arena.data() + at;
+        const uint32_t *w = arena + at;
         ParsedRec r;
-        r.wpos = (uint32_t)(lo + w[0]);
+        r.wpos = wpos_map ? (*wpos_map)[w[0]] : (uint32_t)(lo + w[0]);
         r.a.rank = w[1];
         r.a.begin = (int32_t)w[2];
         r.a.end_i = (int32_t)w[3];
@@ -647,6 +654,44 @@ static int parse_records(const std::vector<uint32_t> &arena, uint64_t used, size
         recs.push_back(r);
         at += SWMI_ALNREC_WORDS + opw;
     }
+    return SWMI_OK;
+}
+
+// Turns the raw record streams of the last run into per-pair alignment lists (first use of an alignment accessor).
+static int ensure_indexed(swmi_batch *b) {
+    if (b->indexed) return SWMI_OK;
+    const std::vector<Work> &work = b->work;
+    std::vector<ParsedRec> recs;
+    b->ops.clear();
+    for (auto &c : b->raw_chunks) {
+        int rc = parse_records(b->raw.data() + c.at, c.words, c.lo, c.wpos.empty() ? nullptr : &c.wpos, b->ops, recs);
+        if (rc) return rc;
+    }
+    // group records by pair, ordered by rank (= OptAlignments order for the serial mode)
+    for (auto &w : work) b->pairs[w.pair].count = 0;
+    for (auto &r : recs) b->pairs[work[r.wpos].pair].count++;
+    uint64_t run = 0;
+    for (auto &w : work) { PairRes &pr = b->pairs[w.pair]; pr.first = run; run += pr.count; }
+    b->alns.assign(run, HostAln{});
+    for (auto &r : recs) {
+        PairRes &pr = b->pairs[work[r.wpos].pair];
+        if (r.a.rank >= pr.count) return fail(SWMI_ERR_HIP, "record rank %u out of range", r.a.rank);
+        b->alns[pr.first + r.a.rank] = r.a;
+    }
+    for (auto &w : work) {
+        PairRes &pr = b->pairs[w.pair];
+        if (!(pr.flags & SWMI_PAIR_DEGENERATE) && pr.count != pr.n_cells)
+            return fail(SWMI_ERR_HIP, "pair %u: %llu records for %llu max cells", w.pair,
+                        (unsigned long long)pr.count, (unsigned long long)pr.n_cells);
+        // DistributedSW.GetAlignments sorts the collected alignments by beginning (DistributedSW.java:480)
+        if (b->params.tie_mode == SWMI_TIE_STRICT && pr.count > 1)
+            std::stable_sort(b->alns.begin() + pr.first, b->alns.begin() + pr.first + pr.count,
+                             [](const HostAln &x, const HostAln &y) { return x.begin < y.begin; });
+    }
+    b->str_ref.assign(run, std::string());
+    b->str_read.assign(run, std::string());
+    for (uint64_t k = 0; k < run; k++) b->alns[k].str_id = -1;
+    b->indexed = true;
     return SWMI_OK;
 }
 
@@ -674,6 +719,7 @@ extern "C" int swmi_batch_run(swmi_ctx *ctx, swmi_batch *b, const swmi_params *p
     const uint64_t n_pairs = (uint64_t)n_refs * n_reads;
     b->pairs.assign(n_pairs, PairRes{});
     b->alns.clear(); b->ops.clear(); b->str_ref.clear(); b->str_read.clear();
+    b->raw.clear(); b->raw_chunks.clear(); b->indexed = false;
     b->ref_view_ready.assign(n_refs, 0);
     b->ref_sites.assign(n_refs, {});
     b->ref_degenerate.assign(n_refs, 0);
@@ -713,8 +759,6 @@ extern "C" int swmi_batch_run(swmi_ctx *ctx, swmi_batch *b, const swmi_params *p
     hipEvent_t ev_total0 = ctx->ev[5];
     (void)ev_total0;
 
-    std::vector<std::vector<ParsedRec>> all_recs;   // per chunk
-    std::vector<ParsedRec> recs;
     std::vector<PairOut> outs;
     std::vector<uint32_t> arena;
     std::vector<size_t> ovf;                         // positions in `work` that overflowed their cell list
@@ -740,7 +784,8 @@ extern "C" int swmi_batch_run(swmi_ctx *ctx, swmi_batch *b, const swmi_params *p
             pr.n_cells = outs[k].n_cells;
             if (outs[k].flags & SWMI_F_CELL_OVF) ovf.push_back(lo + k);
         }
-        if ((rc = parse_records(arena, used, lo, b->ops, recs))) return rc;
+        b->raw_chunks.push_back(swmi_batch::RawChunk{b->raw.size(), (size_t)used, lo, {}});
+        b->raw.insert(b->raw.end(), arena.begin(), arena.begin() + used);
         lo = hi;
     }
 
@@ -761,13 +806,12 @@ extern "C" int swmi_batch_run(swmi_ctx *ctx, swmi_batch *b, const swmi_params *p
             uint64_t used = 0;
             int rc = run_chunk(rs, w2, lo2, hi2, &exact, outs, arena, used);
             if (rc) return rc;
-            std::vector<ParsedRec> r2;
-            if ((rc = parse_records(arena, used, lo2, b->ops, r2))) return rc;
-            for (auto &r : r2) {
-                // translate the position in w2 back to a position in `work`
-                r.wpos = (uint32_t)ovf[r.wpos];
-                recs.push_back(r);
-            }
+            swmi_batch::RawChunk rc2{b->raw.size(), (size_t)used, lo2, {}};
+            rc2.wpos.resize(hi2 - lo2);
+            for (size_t k = 0; k < hi2 - lo2; k++) rc2.wpos[k] = (uint32_t)ovf[lo2 + k];   // chunk-local id -> position in `work`
+            b->raw_chunks.push_back(std::move(rc2));
+            b->raw.insert(b->raw.end(), arena.begin(), arena.begin() + used);
+            for (size_t k = 0; k < hi2 - lo2; k++) b->pairs[w2[lo2 + k].pair].n_cells = outs[k].n_cells;
             for (size_t k = 0; k < hi2 - lo2; k++)
                 if (outs[k].flags & SWMI_F_CELL_OVF)
                     return fail(SWMI_ERR_HIP, "cell list overflowed again on the exact-size re-run");
@@ -775,30 +819,6 @@ extern "C" int swmi_batch_run(swmi_ctx *ctx, swmi_batch *b, const swmi_params *p
         }
         b->timing.rerun_pairs = (uint32_t)ovf.size();
     }
-
-    // group records by pair, ordered by rank (= OptAlignments order for the serial mode)
-    for (auto &r : recs) b->pairs[work[r.wpos].pair].count++;
-    uint64_t run = 0;
-    for (auto &w : work) { PairRes &pr = b->pairs[w.pair]; pr.first = run; run += pr.count; }
-    b->alns.resize(run);
-    for (auto &r : recs) {
-        PairRes &pr = b->pairs[work[r.wpos].pair];
-        if (r.a.rank >= pr.count) return fail(SWMI_ERR_HIP, "record rank %u out of range", r.a.rank);
-        b->alns[pr.first + r.a.rank] = r.a;
-    }
-    for (auto &w : work) {
-        PairRes &pr = b->pairs[w.pair];
-        if (!(pr.flags & SWMI_PAIR_DEGENERATE) && pr.count != pr.n_cells)
-            return fail(SWMI_ERR_HIP, "pair %u: %llu records for %llu max cells", w.pair,
-                        (unsigned long long)pr.count, (unsigned long long)pr.n_cells);
-        // DistributedSW.GetAlignments sorts the collected alignments by beginning (DistributedSW.java:480)
-        if (p->tie_mode == SWMI_TIE_STRICT && pr.count > 1)
-            std::stable_sort(b->alns.begin() + pr.first, b->alns.begin() + pr.first + pr.count,
-                             [](const HostAln &x, const HostAln &y) { return x.begin < y.begin; });
-    }
-    b->str_ref.assign(run, std::string());
-    b->str_read.assign(run, std::string());
-    for (uint64_t k = 0; k < run; k++) b->alns[k].str_id = -1;
 
     b->timing.fill_ms = rs.fill_ms; b->timing.traceback_ms = rs.tb_ms; b->timing.d2h_ms = rs.d2h_ms;
     b->timing.total_ms = rs.fill_ms + rs.tb_ms + rs.d2h_ms;
@@ -883,6 +903,7 @@ extern "C" int swmi_pair_alignment(swmi_batch *b, uint64_t pair, uint64_t k,
                                    const char **ref_aln, const char **read_aln, uint32_t *len) {
     int rc = check_pair(b, pair);
     if (rc) return rc;
+    if ((rc = ensure_indexed(b))) return rc;
     PairRes &pr = b->pairs[pair];
     if (k >= pr.n_cells) return fail(SWMI_ERR_RANGE, "alignment %llu out of range", (unsigned long long)k);
     if (pr.flags & SWMI_PAIR_DEGENERATE) {
@@ -957,6 +978,7 @@ static void build_ref_view(swmi_batch *b, uint32_t ref) {
 extern "C" int swmi_ref_n_match_sites(swmi_batch *b, uint32_t ref, uint64_t *n) {
     int rc = check_ref(b, ref);
     if (rc) return rc;
+    if ((rc = ensure_indexed(b))) return rc;
     build_ref_view(b, ref);
     if (n) *n = b->ref_degenerate[ref] + b->ref_sites[ref].size();
     return SWMI_OK;
@@ -966,6 +988,7 @@ extern "C" int swmi_ref_match_site(swmi_batch *b, uint32_t ref, uint64_t k, int3
                                    const char **ref_aln, const char **read_aln, uint32_t *len) {
     int rc = check_ref(b, ref);
     if (rc) return rc;
+    if ((rc = ensure_indexed(b))) return rc;
     build_ref_view(b, ref);
     const uint64_t deg = b->ref_degenerate[ref];
     if (k < deg) {
