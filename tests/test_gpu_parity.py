@@ -171,3 +171,49 @@ def test_config1_headline_batch_scores_and_winner(ctx):
     assert sum(totals) == ob["sum_score"]
     assert sum(b.n_alignments(r)[0] for r in range(len(refs))) == ob["sum_aln"]
     b.free()
+
+
+def test_chunked_workspace_streaming(ctx):
+    # a workspace cap far below the batch's need forces several launch chunks (how the 10^6-reference config streams)
+    refs, reads = synth.config_ncbi(300, read_len=150, seed=2)
+    ctx.set_option("max_workspace_bytes", 1 << 20)
+    try:
+        b = ctx.upload(refs, reads).run()
+        assert b.timing().fill_launches > 3
+        rng = random.Random(7)
+        for r in rng.sample(range(len(refs)), 40):
+            es, ea = orc.opt_alignments((refs[r], reads[0]))
+            assert b.score(r) == es and b.alignments(r) == ea
+        ob = orc.bench(refs, reads, nthreads=8)
+        assert int(b.ref_totals().astype("int64").sum()) == ob["sum_score"]
+        assert sum(b.n_alignments(r)[0] for r in range(len(refs))) == ob["sum_aln"]
+        b.free()
+    finally:
+        ctx.set_option("max_workspace_bytes", 32 << 30)
+
+
+def test_long_pairs_multi_strip(ctx):
+    # configs[4] shape at reduced length: 3000 x 3000 pairs need 12 strips of 256 read rows each
+    refs, reads = synth.config_long(n_pairs=2, length=3000, seed=4)
+    b = ctx.upload(refs, reads).run()
+    for r in range(2):
+        for q in range(2):
+            es, ea = orc.opt_alignments((refs[r], reads[q]))
+            assert b.score(r * 2 + q) == es
+            assert b.alignments(r * 2 + q) == ea
+    b.free()
+
+
+def test_ncbi_shaped_batch_checksums(ctx):
+    # configs[2] shape (log-normal reference lengths, median 1,609 bp) at 4,000 references: checksum of all scores and
+    # alignment counts against the oracle's multi-threaded pass, plus the winner
+    refs, reads = synth.config_ncbi(4000, read_len=150, seed=2)
+    b = ctx.upload(refs, reads).run()
+    totals = b.ref_totals()
+    ob = orc.bench(refs, reads, nthreads=32)
+    assert int(totals.astype("int64").sum()) == ob["sum_score"]
+    assert sum(b.n_alignments(r)[0] for r in range(len(refs))) == ob["sum_aln"]
+    w = int(totals.argmax())
+    es, ea = orc.opt_alignments((refs[w], reads[0]))
+    assert b.score(w) == es and b.alignments(w) == ea
+    b.free()
