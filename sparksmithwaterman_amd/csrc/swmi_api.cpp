@@ -756,8 +756,6 @@ extern "C" int swmi_batch_run(swmi_ctx *ctx, swmi_batch *b, const swmi_params *p
     const auto h1 = now();
     RunState rs;
     rs.ctx = ctx; rs.b = b;
-    hipEvent_t ev_total0 = ctx->ev[5];
-    (void)ev_total0;
 
     std::vector<PairOut> outs;
     std::vector<uint32_t> arena;
