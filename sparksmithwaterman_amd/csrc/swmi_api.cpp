@@ -567,6 +567,15 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
             for (size_t k = 0; k < np; k++) { a0 += d[4*k]; a1 += d[4*k+1]; a2 += d[4*k+2]; a3 += d[4*k+3]; mx = std::max(mx, d[4*k]); }
             fprintf(stderr, "[swmi tb dbg] wave ticks mean=%.0f max=%llu; walk ticks mean=%.0f; steps mean=%.1f; iterations mean=%.2f\n",
                     a0 / np, mx, a1 / np, a2 / np, a3 / np);
+            const PairOut *po_dbg = (const PairOut *)((const uint8_t *)b->h_result.p + result_out_off());
+            double cs[4] = {0, 0, 0, 0}, cw[4] = {0, 0, 0, 0}; unsigned long long cm[4] = {0, 0, 0, 0}; size_t cn[4] = {0, 0, 0, 0};
+            for (size_t k = 0; k < np; k++) {
+                const size_t c = std::min<uint64_t>(po_dbg[k].n_cells, 4) - (po_dbg[k].n_cells ? 1 : 0);
+                cs[c] += d[4 * k]; cw[c] += d[4 * k + 1]; cm[c] = std::max(cm[c], d[4 * k]); cn[c]++;
+            }
+            for (int c = 0; c < 4; c++)
+                if (cn[c]) fprintf(stderr, "[swmi tb dbg]   %d%s alignment(s): %zu pairs, wave ticks mean=%.0f max=%llu, walk(slot 0) mean=%.0f\n",
+                                   c + 1, c == 3 ? "+" : "", cn[c], cs[c] / cn[c], cm[c], cw[c] / cn[c]);
         }
         if (fa.dbg && attempt == 0) {
             std::vector<unsigned long long> d(np * 2);

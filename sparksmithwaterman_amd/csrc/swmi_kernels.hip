@@ -27,6 +27,7 @@
 //   stages the 2-bit ops in LDS and appends one variable-length record per alignment to an arena.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "swmi_device.h"
 
 #define WAVE 64
@@ -529,6 +530,7 @@ sw_sweep_winmax_kernel(const FillArgs A) { fill_entry<SWMI_MODE_WINMAX>(A); }
 #define SWMI_TB_BLOCKS 16u
 #define SWMI_TB_REFWIN_WORDS 96u      // (16*16 + 63) / 4 + slack
 #define SWMI_TB_SLOTS 4u
+#define SWMI_TB_WAVES 8u            // mode 1: most waves per workgroup (= per pair) of the traceback kernel; the launcher picks 4 or 8
 
 // re-sweep the window of SWMI_CK_BLOCKS blocks that starts at block `wlo` of strip `s` into lds_tile.
 // DETECT: also append the window's cells equal to `maxv` to the pair's cell list; returns the new list length.
@@ -650,10 +652,17 @@ __device__ __forceinline__ uint32_t detect_cells(const TraceArgs &A, const PairD
     return cnt;
 }
 
-template <int R, int TMODE>
+// COOP (mode 1): the workgroup's SWMI_TB_WAVES waves form `nslots` teams of `ts` waves, one walker (this function)
+// plus ts-1 helpers (coop_helper below) each.  Instead of re-sweeping one 32-step window at a time, the walker
+// publishes a request for up to ts consecutive windows, the team re-sweeps them in parallel into the team's tile,
+// and the walker then crosses the whole 32*ts-step span without stopping.  All waves of the workgroup move in
+// rounds delimited by two barriers: (A) requests published, (B) tiles complete.
+// shared[]: [0] number of maximum cells, [1] walkers finished, [4+4t ..] team t's request {strip, first block, windows}.
+template <int R, int TMODE, bool COOP>
 __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDesc pd, const PairOut po,
                                                const uint32_t lane, const uint32_t slot, const uint32_t nslots,
-                                               uint32_t *__restrict__ lds) {
+                                               uint32_t *__restrict__ lds, uint32_t *__restrict__ lds_tile,
+                                               volatile uint32_t *__restrict__ shared, const uint32_t ts) {
     const SeqDesc rd = A.refs[pd.ref_id];
     const SeqDesc qd = A.reads[pd.read_id];
     const uint32_t n = rd.len, m = qd.len;
@@ -668,7 +677,6 @@ __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDes
     uint32_t *lds_ops = lds;                                   // [A.lds_words]      one op per BYTE, staged per alignment
     uint32_t *lds_read = lds_ops + A.lds_words;                // [A.lds_read_words] the read's codes
     uint32_t *lds_ref = lds_read + A.lds_read_words;           // [SWMI_TB_REFWIN_WORDS]
-    uint32_t *lds_tile = lds_ref + SWMI_TB_REFWIN_WORDS;       // [WIN * R * 64]
     uint8_t *ops_b = reinterpret_cast<uint8_t *>(lds_ops);
     const uint8_t *read_b = reinterpret_cast<const uint8_t *>(lds_read);
     const uint8_t *ref_b = reinterpret_cast<const uint8_t *>(lds_ref);
@@ -719,6 +727,10 @@ __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDes
                 if (TMODE == 0) {
                     wlo = whi >= SWMI_TB_BLOCKS - 1u ? whi - (SWMI_TB_BLOCKS - 1u) : 0u;
                     nb = whi - wlo + 1u;
+                } else if (COOP) {
+                    const uint32_t wtop = whi - whi % SWMI_CK_BLOCKS;
+                    wlo = wtop >= (ts - 1u) * SWMI_CK_BLOCKS ? wtop - (ts - 1u) * SWMI_CK_BLOCKS : 0u;
+                    nb = wtop + SWMI_CK_BLOCKS - wlo;
                 } else {
                     wlo = whi - whi % SWMI_CK_BLOCKS;                              // windows start at checkpoints
                     nb = SWMI_CK_BLOCKS;
@@ -728,13 +740,20 @@ __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDes
                     const uint32_t *__restrict__ src = dirp + s * G.strip_words + (uint64_t)wlo * R * WAVE + lane;
                     for (uint32_t x = 0; x < nb * R; ++x) lds_tile[x * WAVE + lane] = src[(uint64_t)x * WAVE];
                 } else {
+                    if (COOP) {
+                        if (lane == 0) { shared[4u + 4u * slot] = s; shared[5u + 4u * slot] = wlo; shared[6u + 4u * slot] = nb / SWMI_CK_BLOCKS; }
+                        __syncthreads();                                           // (A) request visible to the helpers
+                    }
                     (void)replay_any<R, false>(A, pd, n, m, acgt, refw, readw, G, s, wlo, lane, lds_tile, 0, 0u, nullptr, 0u);
                 }
                 const int clo = (int)(16u * wlo) - 63;
                 const uint32_t cw0 = clo > 0 ? (uint32_t)clo >> 2 : 0u;           // first dword of the reference window
                 const uint32_t cw1 = (16u * (wlo + nb) - 1u) >> 2;
                 for (uint32_t x = cw0 + lane; x <= cw1 && x < (n + 3u) / 4u; x += WAVE) lds_ref[x - cw0] = refw[x];
-                WAVE_SYNC();
+                if (COOP) {
+                    __syncthreads();                                               // (B) every wave's window is in the tile
+                    if (lane == 0) shared[6u + 4u * slot] = 0u;                    // request served
+                } else WAVE_SYNC();
                 const int tmin = (int)(16u * wlo);
                 const unsigned long long tw0 = A.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
 
@@ -852,11 +871,47 @@ __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDes
             WAVE_SYNC();
         }
     }
+    if (COOP) {
+        // finished: keep in step with the rounds of the teams still walking
+        if (lane == 0) atomicAdd(const_cast<uint32_t *>(&shared[1]), 1u);
+        for (;;) {
+            __syncthreads();                                                       // (A)
+            if (shared[1] == nslots) break;
+            __syncthreads();                                                       // (B)
+        }
+    }
     if (A.dbg && lane == 0 && slot == 0) {
         A.dbg[4 * pd.out_id] = __builtin_amdgcn_s_memtime() - tk0;
         A.dbg[4 * pd.out_id + 1] = tk_walk;
         A.dbg[4 * pd.out_id + 2] = n_steps;
         A.dbg[4 * pd.out_id + 3] = n_iters;
+    }
+}
+
+// The helper side of COOP: wave `wave` >= nw serves team (wave - nw) % nw as its window number 1 + (wave - nw) / nw.
+template <int R>
+__device__ __forceinline__ void coop_helper(const TraceArgs &A, const PairDesc pd, const uint32_t lane, const uint32_t wave,
+                                            const uint32_t nw, const uint32_t ts,
+                                            uint32_t *__restrict__ tiles, volatile uint32_t *__restrict__ shared) {
+    const SeqDesc rd = A.refs[pd.ref_id];
+    const SeqDesc qd = A.reads[pd.read_id];
+    const uint32_t n = rd.len, m = qd.len;
+    const uint32_t *__restrict__ refw = A.seqw + rd.boff;
+    const uint32_t *__restrict__ readw = A.seqw + qd.boff;
+    const StripGeom G = strip_geom<R>(m, n, 1u);
+    const bool acgt = rd.acgt && qd.acgt && A.match >= -128 && A.match <= 127 && A.mismatch >= -128 && A.mismatch <= 127;
+    const uint32_t team = (wave - nw) % nw, q = 1u + (wave - nw) / nw;
+    uint32_t *__restrict__ tile = tiles + (team * ts + q) * (SWMI_CK_BLOCKS * SWMI_RMAX * WAVE) ;
+    (void)tile;
+    for (;;) {
+        __syncthreads();                                                           // (A)
+        if (shared[1] == nw) break;
+        const uint32_t s = shared[4u + 4u * team], wlo = shared[5u + 4u * team], nq = shared[6u + 4u * team];
+        if (q < ts && q < nq)
+            (void)replay_any<R, false>(A, pd, n, m, acgt, refw, readw, G, s, wlo + q * SWMI_CK_BLOCKS, lane,
+                                       tiles + team * ts * (SWMI_CK_BLOCKS * SWMI_RMAX * WAVE) + q * SWMI_CK_BLOCKS * R * WAVE,
+                                       0, 0u, nullptr, 0u);
+        __syncthreads();                                                           // (B)
     }
 }
 
@@ -871,21 +926,22 @@ __device__ __forceinline__ void traceback_entry(const TraceArgs &A, uint32_t *ld
     const uint32_t slot = blockIdx.y;
     uint32_t *tb_lds = lds_all + wave * (A.lds_words + A.lds_read_words + SWMI_TB_REFWIN_WORDS +
                                          (TMODE == 0 ? SWMI_TB_BLOCKS : SWMI_CK_BLOCKS) * SWMI_RMAX * WAVE);
+    uint32_t *tile = tb_lds + A.lds_words + A.lds_read_words + SWMI_TB_REFWIN_WORDS;
     const PairDesc pd = A.pairs[pair];
     const PairOut po = A.out[pd.out_id];
     if (A.out_host && slot == 0 && lane == 0) A.out_host[pd.out_id] = po;      // result straight into pinned host memory
     if (po.flags & (SWMI_F_DEGENERATE | SWMI_F_CELL_OVF)) return;
     if (po.n_cells <= slot) return;
     const uint32_t R = swmi_rows_per_lane(A.reads[pd.read_id].len);
-    if (R == 1)      traceback_pair<1, TMODE>(A, pd, po, lane, slot, SWMI_TB_SLOTS, tb_lds);
-    else if (R == 2) traceback_pair<2, TMODE>(A, pd, po, lane, slot, SWMI_TB_SLOTS, tb_lds);
-    else if (R == 3) traceback_pair<3, TMODE>(A, pd, po, lane, slot, SWMI_TB_SLOTS, tb_lds);
-    else             traceback_pair<4, TMODE>(A, pd, po, lane, slot, SWMI_TB_SLOTS, tb_lds);
+    if (R == 1)      traceback_pair<1, TMODE, false>(A, pd, po, lane, slot, SWMI_TB_SLOTS, tb_lds, tile, nullptr, 1u);
+    else if (R == 2) traceback_pair<2, TMODE, false>(A, pd, po, lane, slot, SWMI_TB_SLOTS, tb_lds, tile, nullptr, 1u);
+    else if (R == 3) traceback_pair<3, TMODE, false>(A, pd, po, lane, slot, SWMI_TB_SLOTS, tb_lds, tile, nullptr, 1u);
+    else             traceback_pair<4, TMODE, false>(A, pd, po, lane, slot, SWMI_TB_SLOTS, tb_lds, tile, nullptr, 1u);
 }
 
-// mode 1: one workgroup = the 4 walk slots of ONE pair.  Wave 0 first lists the maximum cells (detect_cells),
-// the workgroup meets at a barrier, then every wave walks its share of the alignments.
-extern "C" __global__ void __launch_bounds__(WAVE * FILL_WAVES)
+// mode 1: one workgroup of SWMI_TB_WAVES waves = ONE pair.  Wave 0 first lists the maximum cells (detect_cells),
+// the workgroup meets at a barrier, then min(cells, 4) waves walk the alignments and the others help them.
+extern "C" __global__ void __launch_bounds__(WAVE * SWMI_TB_WAVES)
 sw_traceback_winmax_kernel(const TraceArgs A) {
     extern __shared__ uint32_t wm_lds[];
     const uint32_t pair = blockIdx.x;
@@ -893,39 +949,65 @@ sw_traceback_winmax_kernel(const TraceArgs A) {
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const PairDesc pd = A.pairs[pair];
     PairOut po = A.out[pd.out_id];
-    if (po.flags & SWMI_F_DEGENERATE) {                      // same decision in all 4 waves: nobody waits at the barrier
+    if (po.flags & SWMI_F_DEGENERATE) {                      // same decision in every wave: nobody waits at the barrier
         if (A.out_host && wave == 0 && lane == 0) A.out_host[pd.out_id] = po;
         return;
     }
-    const uint32_t per_wave = A.lds_words + A.lds_read_words + SWMI_TB_REFWIN_WORDS + SWMI_CK_BLOCKS * SWMI_RMAX * WAVE;
-    uint32_t *shared = wm_lds;                               // [0] = number of maximum cells
-    uint32_t *lds = wm_lds + 4 + wave * per_wave;
+    // LDS: [24 shared words][tiles: one window per wave][per walker: ops staging, read codes, reference window]
+    const uint32_t n_waves = blockDim.x >> 6;
+    const uint32_t per_walker = A.lds_words + A.lds_read_words + SWMI_TB_REFWIN_WORDS;
+    constexpr uint32_t WIN_WORDS = SWMI_CK_BLOCKS * SWMI_RMAX * WAVE;
+    uint32_t *shared = wm_lds;
+    uint32_t *tiles = wm_lds + 24;
     const uint32_t R = swmi_rows_per_lane(A.reads[pd.read_id].len);
     const uint32_t ccap = A.cells_cap ? A.cells_cap[pd.out_id] : A.cell_cap;
     if (wave == 0) {
-        uint32_t *tile = lds + A.lds_words + A.lds_read_words + SWMI_TB_REFWIN_WORDS;
         uint32_t cnt;
-        if (R == 1)      cnt = detect_cells<1>(A, pd, po, lane, tile);
-        else if (R == 2) cnt = detect_cells<2>(A, pd, po, lane, tile);
-        else if (R == 3) cnt = detect_cells<3>(A, pd, po, lane, tile);
-        else             cnt = detect_cells<4>(A, pd, po, lane, tile);
+        if (R == 1)      cnt = detect_cells<1>(A, pd, po, lane, tiles);
+        else if (R == 2) cnt = detect_cells<2>(A, pd, po, lane, tiles);
+        else if (R == 3) cnt = detect_cells<3>(A, pd, po, lane, tiles);
+        else             cnt = detect_cells<4>(A, pd, po, lane, tiles);
         if (lane == 0) {
             po.n_cells = cnt;
             if (cnt > ccap) po.flags |= SWMI_F_CELL_OVF;
             A.out[pd.out_id] = po;
             if (A.out_host) A.out_host[pd.out_id] = po;
             shared[0] = cnt;
+            shared[1] = 0u;
         }
+        if (lane < SWMI_TB_SLOTS) shared[6u + 4u * lane] = 0u;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the cell list has left the CU before the others read it
     }
     __syncthreads();
     const uint32_t cnt = shared[0];
-    if (cnt > ccap || wave >= cnt) return;
+    if (cnt > ccap || cnt == 0u) return;
     po.n_cells = cnt;
-    if (R == 1)      traceback_pair<1, 1>(A, pd, po, lane, wave, FILL_WAVES, lds);
-    else if (R == 2) traceback_pair<2, 1>(A, pd, po, lane, wave, FILL_WAVES, lds);
-    else if (R == 3) traceback_pair<3, 1>(A, pd, po, lane, wave, FILL_WAVES, lds);
-    else             traceback_pair<4, 1>(A, pd, po, lane, wave, FILL_WAVES, lds);
+    const uint32_t nw = cnt < SWMI_TB_SLOTS ? cnt : SWMI_TB_SLOTS;     // walkers = teams
+    const uint32_t ts = n_waves / nw;                                  // waves (= windows per round) per team
+    if (ts == 1u) {
+        // no helpers to share the re-sweeps with: the walkers run independently, one window at a time
+        if (wave >= nw) return;
+        uint32_t *lds = tiles + n_waves * WIN_WORDS + wave * per_walker;
+        uint32_t *tile = tiles + wave * WIN_WORDS;
+        if (R == 1)      traceback_pair<1, 1, false>(A, pd, po, lane, wave, nw, lds, tile, nullptr, 1u);
+        else if (R == 2) traceback_pair<2, 1, false>(A, pd, po, lane, wave, nw, lds, tile, nullptr, 1u);
+        else if (R == 3) traceback_pair<3, 1, false>(A, pd, po, lane, wave, nw, lds, tile, nullptr, 1u);
+        else             traceback_pair<4, 1, false>(A, pd, po, lane, wave, nw, lds, tile, nullptr, 1u);
+        return;
+    }
+    if (wave < nw) {
+        uint32_t *lds = tiles + n_waves * WIN_WORDS + wave * per_walker;
+        uint32_t *tile = tiles + wave * ts * WIN_WORDS;
+        if (R == 1)      traceback_pair<1, 1, true>(A, pd, po, lane, wave, nw, lds, tile, shared, ts);
+        else if (R == 2) traceback_pair<2, 1, true>(A, pd, po, lane, wave, nw, lds, tile, shared, ts);
+        else if (R == 3) traceback_pair<3, 1, true>(A, pd, po, lane, wave, nw, lds, tile, shared, ts);
+        else             traceback_pair<4, 1, true>(A, pd, po, lane, wave, nw, lds, tile, shared, ts);
+    } else {
+        if (R == 1)      coop_helper<1>(A, pd, lane, wave, nw, ts, tiles, shared);
+        else if (R == 2) coop_helper<2>(A, pd, lane, wave, nw, ts, tiles, shared);
+        else if (R == 3) coop_helper<3>(A, pd, lane, wave, nw, ts, tiles, shared);
+        else             coop_helper<4>(A, pd, lane, wave, nw, ts, tiles, shared);
+    }
 }
 
 extern "C" __global__ void __launch_bounds__(WAVE * FILL_WAVES)
@@ -958,7 +1040,13 @@ extern "C" hipError_t swmi_launch_traceback(const TraceArgs *a, hipStream_t st) 
     const size_t per_wave = (size_t)a->lds_words + a->lds_read_words + SWMI_TB_REFWIN_WORDS + tile;
     const dim3 block(WAVE * FILL_WAVES);
     if (a->mode == 1) {
-        hipLaunchKernelGGL(sw_traceback_winmax_kernel, dim3(a->n_pairs), block, (per_wave * FILL_WAVES + 4) * sizeof(uint32_t), st, *a);
+        // 8 waves per pair (bigger teams, shorter critical path) while every workgroup of the launch can be resident
+        // at once (4 waves per SIMD at this kernel's register count), else 4
+        static int forced = getenv("SWMI_TB_WAVES") ? atoi(getenv("SWMI_TB_WAVES")) : 0;
+        const uint32_t n_waves = forced ? (uint32_t)forced : (a->n_pairs <= 512u ? SWMI_TB_WAVES : 4u);
+        const size_t words = 24 + (size_t)n_waves * SWMI_CK_BLOCKS * SWMI_RMAX * WAVE +
+                             (size_t)SWMI_TB_SLOTS * ((size_t)a->lds_words + a->lds_read_words + SWMI_TB_REFWIN_WORDS);
+        hipLaunchKernelGGL(sw_traceback_winmax_kernel, dim3(a->n_pairs), dim3(WAVE * n_waves), words * sizeof(uint32_t), st, *a);
     } else {
         const dim3 grid((a->n_pairs + FILL_WAVES - 1) / FILL_WAVES, SWMI_TB_SLOTS);
         if (a->mode == 0) hipLaunchKernelGGL(sw_traceback_kernel, grid, block, per_wave * FILL_WAVES * sizeof(uint32_t), st, *a);
