@@ -672,6 +672,9 @@ __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDes
     const uint32_t rps = G.rps;
     const uint32_t *__restrict__ dirp = A.dir + pd.dir_off;
     const uint32_t umat = (uint32_t)A.match, umis = (uint32_t)A.mismatch, ugap = (uint32_t)A.gap;
+    const int dec0 = A.match > A.mismatch ? A.match : A.mismatch;
+    const uint32_t udec = dec0 > 0 ? (uint32_t)dec0 : 0u;    // the most one alignment move can lower the tracked score
+    const uint32_t ugdec = A.gap > 0 ? (uint32_t)A.gap : 0u;  // ... and one gap move
     const bool acgt = rd.acgt && qd.acgt && A.match >= -128 && A.match <= 127 && A.mismatch >= -128 && A.mismatch <= 127;
 
     uint32_t *lds_ops = lds;                                   // [A.lds_words]      one op per BYTE, staged per alignment
@@ -771,21 +774,45 @@ __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDes
                     const uint32_t jj = j - dj - x;                                // column of this lane's cell
                     const int tx = (int)jj - 1 + (int)lx;
                     const bool valid = grp < 3u && rho_x >= 0 && j > dj + x && tx >= tmin;
-                    // all three LDS reads are issued together (one latency): direction word, reference code, read code
-                    uint32_t d = 0;
-                    bool mt = false;
-                    if (valid) {
-                        const uint32_t dw = lds_tile[(((uint32_t)tx >> 4) - wlo) * (R * WAVE) + kx * WAVE + lx];
-                        const uint32_t rc = ref_b[(jj - 1u) - 4u * cw0];
-                        const uint32_t qc = read_b[i - 1u - di - x];
-                        d = (dw >> (2u * (15u - ((uint32_t)tx & 15u)))) & 3u;
-                        mt = rc == qc;
-                    }
+                    // all three LDS reads are issued together (one latency): direction word, reference code, read code.
+                    // Lanes without a cell read element 0 instead of branching around the loads.
+                    const uint32_t dw = lds_tile[valid ? (((uint32_t)tx >> 4) - wlo) * (R * WAVE) + kx * WAVE + lx : 0u];
+                    const uint32_t rc = ref_b[valid ? (jj - 1u) - 4u * cw0 : 0u];
+                    const uint32_t qc = read_b[valid ? i - 1u - di - x : 0u];
+                    const uint32_t d = (dw >> (2u * (15u - ((uint32_t)tx & 15u)))) & 3u;
+                    const bool mt = rc == qc;
                     const uint64_t vmask = BALLOT(valid);
                     if (!(vmask & 1ull)) break;                                    // current cell left the window / the strip: restage
-                    const uint64_t amask = BALLOT(valid && (d & 1u));            // alignment chosen
-                    const uint64_t imask = BALLOT(valid && (d & 3u) == 2u);      // insertion chosen (else deletion)
+                    const uint64_t amask = BALLOT((d & 1u) != 0u) & vmask;       // alignment chosen
+                    const uint64_t imask = BALLOT(d == 2u) & vmask;              // insertion chosen (else deletion)
                     const uint64_t mm = BALLOT(mt);
+                    {
+                        // ---- fast path: [gap move] + [run of alignment moves] + [gap move], taken in one go when the tracked
+                        // score provably stays positive throughout (no move lowers it by more than udec / ugdec) and the cell
+                        // after the first gap move was inspected.  A positive score also rules out reaching row/column 0.
+                        const uint32_t g1 = (uint32_t)(~amask & 1ull);
+                        const uint32_t isI1 = (uint32_t)(imask & 1ull);
+                        const uint32_t fb = g1 ? (isI1 ? 21u : 42u) : 0u;
+                        const uint32_t vb = (uint32_t)(vmask >> fb) & 0x1FFFFFu;
+                        const uint32_t frun = (uint32_t)__builtin_ctz(~((uint32_t)(amask >> fb) & 0x1FFFFFu));   // 0..21
+                        const uint32_t has3 = (vb >> frun) & 1u;                   // bit 21 is never set
+                        if ((!g1 || (vb & 1u)) && (int)score > (int)((g1 + has3) * ugdec + frun * udec)) {
+                            const uint32_t isI3 = (uint32_t)(imask >> (fb + frun)) & 1u & has3;
+                            const uint32_t nm = (uint32_t)__builtin_popcountll(mm & ((((1ull << frun) - 1ull)) << fb));
+                            const uint32_t i1 = g1 & isI1, total = g1 + frun + has3;
+                            score -= (g1 + has3) * ugap + nm * umat + (frun - nm) * umis;
+                            const uint32_t j1 = j - (g1 - i1);                     // column after the first gap move
+                            begin = has3 ? (int)(j1 - frun) : (frun ? (int)(j1 - frun + 1u) : (int)j);
+                            if (lane < total && n_ops + lane < 4u * A.lds_words)
+                                ops_b[n_ops + lane] = (uint8_t)(lane < g1 ? (isI1 ? SWMI_DIR_I : SWMI_DIR_D)
+                                                               : lane < g1 + frun ? SWMI_DIR_A : (isI3 ? SWMI_DIR_I : SWMI_DIR_D));
+                            n_ops += total;
+                            const uint32_t dec_i = i1 + frun + isI3;
+                            i -= dec_i; rho -= (int)dec_i;
+                            j = j1 - frun - (has3 - isI3);
+                            continue;
+                        }
+                    }
                     bool done = false;
                     uint32_t base = 0;                                             // first lane of the diagonal the run is on
                     if (!(amask & 1ull)) {
@@ -804,12 +831,18 @@ __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDes
                     uint32_t run = (uint32_t)__builtin_ctzll(~((amask >> base) & 0x1FFFFFull));     // 0..21
                     if (run > 0) {
                         const uint64_t range = ((1ull << run) - 1ull) << base;
-                        const bool in_run = (range >> lane) & 1ull;
-                        const uint32_t cm = lanemask_lt_count(mm & range) + (mt ? 1u : 0u);   // matches among the run's lanes up to this one
-                        const uint32_t after = score - (cm * umat + (lane - base + 1u - cm) * umis);   // H after this lane's move
-                        const uint64_t z = BALLOT(in_run && (int)after <= 0);
-                        if (z) { run = (uint32_t)__builtin_ctzll(z) - base + 1u; done = true; }   // `while (score > 0)` stops there
-                        score = (uint32_t)__builtin_amdgcn_readlane((int)after, base + run - 1u);
+                        if ((int)score > (int)(run * udec)) {
+                            // no move lowers the score by more than udec: it stays positive through the whole run
+                            const uint32_t nm = (uint32_t)__builtin_popcountll(mm & range);
+                            score -= nm * umat + (run - nm) * umis;
+                        } else {
+                            const bool in_run = (range >> lane) & 1ull;
+                            const uint32_t cm = lanemask_lt_count(mm & range) + (mt ? 1u : 0u);   // matches among the run's lanes up to this one
+                            const uint32_t after = score - (cm * umat + (lane - base + 1u - cm) * umis);   // H after this lane's move
+                            const uint64_t z = BALLOT(in_run && (int)after <= 0);
+                            if (z) { run = (uint32_t)__builtin_ctzll(z) - base + 1u; done = true; }   // `while (score > 0)` stops there
+                            score = (uint32_t)__builtin_amdgcn_readlane((int)after, base + run - 1u);
+                        }
                         begin = (int)(j - (run - 1u));
                         if (lane >= base && lane < base + run && n_ops + (lane - base) < 4u * A.lds_words)
                             ops_b[n_ops + (lane - base)] = (uint8_t)SWMI_DIR_A;
