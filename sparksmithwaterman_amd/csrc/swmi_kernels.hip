@@ -662,7 +662,8 @@ template <int R, int TMODE, bool COOP>
 __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDesc pd, const PairOut po,
                                                const uint32_t lane, const uint32_t slot, const uint32_t nslots,
                                                uint32_t *__restrict__ lds, uint32_t *__restrict__ lds_tile,
-                                               volatile uint32_t *__restrict__ shared, const uint32_t ts) {
+                                               volatile uint32_t *__restrict__ shared, const uint32_t ts,
+                                               uint32_t pre_wlo = 0xFFFFFFFFu) {
     const SeqDesc rd = A.refs[pd.ref_id];
     const SeqDesc qd = A.reads[pd.read_id];
     const uint32_t n = rd.len, m = qd.len;
@@ -738,25 +739,30 @@ __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDes
                     wlo = whi - whi % SWMI_CK_BLOCKS;                              // windows start at checkpoints
                     nb = SWMI_CK_BLOCKS;
                 }
-                WAVE_SYNC();
-                if (TMODE == 0) {
-                    const uint32_t *__restrict__ src = dirp + s * G.strip_words + (uint64_t)wlo * R * WAVE + lane;
-                    for (uint32_t x = 0; x < nb * R; ++x) lds_tile[x * WAVE + lane] = src[(uint64_t)x * WAVE];
-                } else {
-                    if (COOP) {
-                        if (lane == 0) { shared[4u + 4u * slot] = s; shared[5u + 4u * slot] = wlo; shared[6u + 4u * slot] = nb / SWMI_CK_BLOCKS; }
-                        __syncthreads();                                           // (A) request visible to the helpers
-                    }
-                    (void)replay_any<R, false>(A, pd, n, m, acgt, refw, readw, G, s, wlo, lane, lds_tile, 0, 0u, nullptr, 0u);
-                }
+                // COOP: the span of the first staging was already re-swept while wave 0 listed the maximum cells
+                const bool prestaged = COOP && pre_wlo == wlo && s == 0u;
+                pre_wlo = 0xFFFFFFFFu;
                 const int clo = (int)(16u * wlo) - 63;
                 const uint32_t cw0 = clo > 0 ? (uint32_t)clo >> 2 : 0u;           // first dword of the reference window
                 const uint32_t cw1 = (16u * (wlo + nb) - 1u) >> 2;
-                for (uint32_t x = cw0 + lane; x <= cw1 && x < (n + 3u) / 4u; x += WAVE) lds_ref[x - cw0] = refw[x];
-                if (COOP) {
-                    __syncthreads();                                               // (B) every wave's window is in the tile
-                    if (lane == 0) shared[6u + 4u * slot] = 0u;                    // request served
-                } else WAVE_SYNC();
+                WAVE_SYNC();
+                if (!prestaged) {
+                    if (TMODE == 0) {
+                        const uint32_t *__restrict__ src = dirp + s * G.strip_words + (uint64_t)wlo * R * WAVE + lane;
+                        for (uint32_t x = 0; x < nb * R; ++x) lds_tile[x * WAVE + lane] = src[(uint64_t)x * WAVE];
+                    } else {
+                        if (COOP) {
+                            if (lane == 0) { shared[4u + 4u * slot] = s; shared[5u + 4u * slot] = wlo; shared[6u + 4u * slot] = nb / SWMI_CK_BLOCKS; }
+                            __syncthreads();                                       // (A) request visible to the helpers
+                        }
+                        (void)replay_any<R, false>(A, pd, n, m, acgt, refw, readw, G, s, wlo, lane, lds_tile, 0, 0u, nullptr, 0u);
+                    }
+                    for (uint32_t x = cw0 + lane; x <= cw1 && x < (n + 3u) / 4u; x += WAVE) lds_ref[x - cw0] = refw[x];
+                    if (COOP) {
+                        __syncthreads();                                           // (B) every wave's window is in the tile
+                        if (lane == 0) shared[6u + 4u * slot] = 0u;                // request served
+                    } else WAVE_SYNC();
+                }
                 const int tmin = (int)(16u * wlo);
                 const unsigned long long tw0 = A.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
 
@@ -972,6 +978,65 @@ __device__ __forceinline__ void traceback_entry(const TraceArgs &A, uint32_t *ld
     else             traceback_pair<4, TMODE, false>(A, pd, po, lane, slot, SWMI_TB_SLOTS, tb_lds, tile, nullptr, 1u);
 }
 
+// mode 1, before the walks: wave 0 lists the maximum cells.  In the usual case -- one strip, ONE window holding the
+// pair's maximum -- the other waves meanwhile re-sweep the windows below it (and copy the slice of the reference), so
+// that the span a single alignment's walk starts in is complete when the cell list is.  Returns the first block of
+// that span, or ~0 when nothing was pre-staged.  shared[0] receives the number of cells.
+template <int R>
+__device__ __forceinline__ uint32_t winmax_detect(const TraceArgs &A, const PairDesc pd, PairOut &po, const uint32_t lane,
+                                                  const uint32_t wave, const uint32_t n_waves, const uint32_t ccap,
+                                                  uint32_t *__restrict__ tiles, uint32_t *__restrict__ walker0_ref,
+                                                  volatile uint32_t *__restrict__ shared) {
+    const SeqDesc rd = A.refs[pd.ref_id];
+    const SeqDesc qd = A.reads[pd.read_id];
+    const uint32_t n = rd.len, m = qd.len;
+    const StripGeom G = strip_geom<R>(m, n, 1u);
+    uint32_t ncand = 0, gfirst = 0;
+    if (G.n_strips == 1u) {
+        const uint32_t *__restrict__ wm = A.dir + pd.dir_off + G.wmax_off;
+        for (uint32_t g0 = 0; g0 < G.n_ck; g0 += WAVE) {
+            const uint32_t g = g0 + lane;
+            const int wv = g < G.n_ck ? (int)wm[g] : -1;
+            const uint64_t cand = BALLOT(wv == po.score);
+            if (cand) {
+                if (!ncand) gfirst = g0 + (uint32_t)__builtin_ctzll(cand);
+                ncand += (uint32_t)__builtin_popcountll(cand);
+            }
+        }
+    }
+    const bool pre = ncand == 1u;
+    const uint32_t nq0 = gfirst + 1u < n_waves ? gfirst + 1u : n_waves;           // windows of the span that ends with window gfirst
+    const uint32_t wlo0 = (gfirst + 1u - nq0) * SWMI_CK_BLOCKS;
+    if (wave == 0) {
+        const uint32_t cnt = detect_cells<R>(A, pd, po, lane, pre ? tiles + (nq0 - 1u) * SWMI_CK_BLOCKS * R * WAVE : tiles);
+        if (lane == 0) {
+            po.n_cells = cnt;
+            if (cnt > ccap) po.flags |= SWMI_F_CELL_OVF;
+            A.out[pd.out_id] = po;
+            if (A.out_host) A.out_host[pd.out_id] = po;
+            shared[0] = cnt;
+            shared[1] = 0u;
+        }
+        if (lane < SWMI_TB_SLOTS) shared[6u + 4u * lane] = 0u;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the cell list has left the CU before the others read it
+    } else if (pre) {
+        const uint32_t *__restrict__ refw = A.seqw + rd.boff;
+        if (wave < nq0) {
+            const uint32_t *__restrict__ readw = A.seqw + qd.boff;
+            const bool acgt = rd.acgt && qd.acgt && A.match >= -128 && A.match <= 127 && A.mismatch >= -128 && A.mismatch <= 127;
+            (void)replay_any<R, false>(A, pd, n, m, acgt, refw, readw, G, 0u, wlo0 + (wave - 1u) * SWMI_CK_BLOCKS, lane,
+                                       tiles + (wave - 1u) * SWMI_CK_BLOCKS * R * WAVE, 0, 0u, nullptr, 0u);
+        }
+        if (wave == n_waves - 1u) {                          // the wave least likely to have a window to re-sweep
+            const int clo = (int)(16u * wlo0) - 63;
+            const uint32_t cw0 = clo > 0 ? (uint32_t)clo >> 2 : 0u;
+            const uint32_t cw1 = (16u * (wlo0 + nq0 * SWMI_CK_BLOCKS) - 1u) >> 2;
+            for (uint32_t x = cw0 + lane; x <= cw1 && x < (n + 3u) / 4u; x += WAVE) walker0_ref[x - cw0] = refw[x];
+        }
+    }
+    return pre ? wlo0 : 0xFFFFFFFFu;
+}
+
 // mode 1: one workgroup of SWMI_TB_WAVES waves = ONE pair.  Wave 0 first lists the maximum cells (detect_cells),
 // the workgroup meets at a barrier, then min(cells, 4) waves walk the alignments and the others help them.
 extern "C" __global__ void __launch_bounds__(WAVE * SWMI_TB_WAVES)
@@ -994,23 +1059,12 @@ sw_traceback_winmax_kernel(const TraceArgs A) {
     uint32_t *tiles = wm_lds + 24;
     const uint32_t R = swmi_rows_per_lane(A.reads[pd.read_id].len);
     const uint32_t ccap = A.cells_cap ? A.cells_cap[pd.out_id] : A.cell_cap;
-    if (wave == 0) {
-        uint32_t cnt;
-        if (R == 1)      cnt = detect_cells<1>(A, pd, po, lane, tiles);
-        else if (R == 2) cnt = detect_cells<2>(A, pd, po, lane, tiles);
-        else if (R == 3) cnt = detect_cells<3>(A, pd, po, lane, tiles);
-        else             cnt = detect_cells<4>(A, pd, po, lane, tiles);
-        if (lane == 0) {
-            po.n_cells = cnt;
-            if (cnt > ccap) po.flags |= SWMI_F_CELL_OVF;
-            A.out[pd.out_id] = po;
-            if (A.out_host) A.out_host[pd.out_id] = po;
-            shared[0] = cnt;
-            shared[1] = 0u;
-        }
-        if (lane < SWMI_TB_SLOTS) shared[6u + 4u * lane] = 0u;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the cell list has left the CU before the others read it
-    }
+    uint32_t *walker0_ref = tiles + n_waves * WIN_WORDS + A.lds_words + A.lds_read_words;
+    uint32_t pre_wlo;
+    if (R == 1)      pre_wlo = winmax_detect<1>(A, pd, po, lane, wave, n_waves, ccap, tiles, walker0_ref, shared);
+    else if (R == 2) pre_wlo = winmax_detect<2>(A, pd, po, lane, wave, n_waves, ccap, tiles, walker0_ref, shared);
+    else if (R == 3) pre_wlo = winmax_detect<3>(A, pd, po, lane, wave, n_waves, ccap, tiles, walker0_ref, shared);
+    else             pre_wlo = winmax_detect<4>(A, pd, po, lane, wave, n_waves, ccap, tiles, walker0_ref, shared);
     __syncthreads();
     const uint32_t cnt = shared[0];
     if (cnt > ccap || cnt == 0u) return;
@@ -1031,10 +1085,10 @@ sw_traceback_winmax_kernel(const TraceArgs A) {
     if (wave < nw) {
         uint32_t *lds = tiles + n_waves * WIN_WORDS + wave * per_walker;
         uint32_t *tile = tiles + wave * ts * WIN_WORDS;
-        if (R == 1)      traceback_pair<1, 1, true>(A, pd, po, lane, wave, nw, lds, tile, shared, ts);
-        else if (R == 2) traceback_pair<2, 1, true>(A, pd, po, lane, wave, nw, lds, tile, shared, ts);
-        else if (R == 3) traceback_pair<3, 1, true>(A, pd, po, lane, wave, nw, lds, tile, shared, ts);
-        else             traceback_pair<4, 1, true>(A, pd, po, lane, wave, nw, lds, tile, shared, ts);
+        if (R == 1)      traceback_pair<1, 1, true>(A, pd, po, lane, wave, nw, lds, tile, shared, ts, nw == 1u ? pre_wlo : 0xFFFFFFFFu);
+        else if (R == 2) traceback_pair<2, 1, true>(A, pd, po, lane, wave, nw, lds, tile, shared, ts, nw == 1u ? pre_wlo : 0xFFFFFFFFu);
+        else if (R == 3) traceback_pair<3, 1, true>(A, pd, po, lane, wave, nw, lds, tile, shared, ts, nw == 1u ? pre_wlo : 0xFFFFFFFFu);
+        else             traceback_pair<4, 1, true>(A, pd, po, lane, wave, nw, lds, tile, shared, ts, nw == 1u ? pre_wlo : 0xFFFFFFFFu);
     } else {
         if (R == 1)      coop_helper<1>(A, pd, lane, wave, nw, ts, tiles, shared);
         else if (R == 2) coop_helper<2>(A, pd, lane, wave, nw, ts, tiles, shared);
