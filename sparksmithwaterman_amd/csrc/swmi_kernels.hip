@@ -90,7 +90,7 @@ struct CellsRef {
         for (int k = 0; k < R; ++k) {
             const int left = hin[k];
             int sc;
-            if (ACGT) sc = __builtin_amdgcn_sbfe(q[k], (unsigned)rb, 8u);
+            if (ACGT) sc = rb ? __builtin_amdgcn_sbfe(q[k], (unsigned)__builtin_ctz((unsigned)rb), 8u) : 0;   // rb = 1 << 8*base
             else      sc = (rb == q[k]) ? vmat : vmis;
             const int a = diag + sc;                       // SmithWaterman.java:244 / AlignmentScore :309-318
             const int t2 = (up > left ? up : left) + gap;   // :227, :235 (InsDelScore :277-280)
@@ -251,7 +251,10 @@ __device__ __forceinline__ void fill_block16(FillState<R> &S, const uint4 w, con
         const int (&hin)[R] = (s & 1u) ? S.g : S.h;
         int (&hout)[R] = (s & 1u) ? S.h : S.g;
         const uint32_t wsel = s < 4 ? w.x : s < 8 ? w.y : s < 12 ? w.z : w.w;
-        const int feed = (int)((wsel >> (8u * (s & 3u))) & 0xFFu);        // base code of column t0+s+1 (lane 0)
+        const uint32_t code = (wsel >> (8u * (s & 3u))) & 0xFFu;          // base code of column t0+s+1 (lane 0)
+        // ACGT: codes are 0, 8, 16, 24 and travel down the lanes ONE-HOT (1 << code) so that one v_dot4_i32_i8 with
+        // the row's score profile yields NW + s(ref, read)
+        const int feed = ACGT ? (int)(1u << (code & 31u)) : (int)code;
         S.rb = wave_shr1(feed, S.rb);
         int nin;
         if (MULTI) {
@@ -288,8 +291,20 @@ __device__ __forceinline__ void fill_block16(FillState<R> &S, const uint4 w, con
                 for (int k = 1; k < R; ++k) mrow = mrow > hout[k] ? mrow : hout[k];
             }
             if (LMAX) {
+                if (R == 3) {
+                    // 6 new values per two steps = three v_max3: the last row of an even step waits for the odd one
+                    // (its register is still live there thanks to the ping-pong)
+                    if (s & 1u) {
+                        int x = S.lmax > hin[2] ? S.lmax : hin[2];  x = x > hout[0] ? x : hout[0];
+                        x = x > hout[1] ? x : hout[1];              S.lmax = x > hout[2] ? x : hout[2];
+                    } else {
+                        const int x = S.lmax > hout[0] ? S.lmax : hout[0];
+                        S.lmax = x > hout[1] ? x : hout[1];
+                    }
+                } else {
 #pragma unroll
-                for (int k = 0; k < R; ++k) S.lmax = S.lmax > hout[k] ? S.lmax : hout[k];
+                    for (int k = 0; k < R; ++k) S.lmax = S.lmax > hout[k] ? S.lmax : hout[k];
+                }
             }
             if (MULTI && FEEDS && feeds_seam && lane == WAVE - 1) seam_out[t0 + s - lane + 1] = hout[R - 1];
         }
@@ -663,7 +678,7 @@ __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDes
                                                const uint32_t lane, const uint32_t slot, const uint32_t nslots,
                                                uint32_t *__restrict__ lds, uint32_t *__restrict__ lds_tile,
                                                volatile uint32_t *__restrict__ shared, const uint32_t ts,
-                                               uint32_t pre_wlo = 0xFFFFFFFFu) {
+                                               uint32_t pre_wlo = 0xFFFFFFFFu, const bool read_staged = false) {
     const SeqDesc rd = A.refs[pd.ref_id];
     const SeqDesc qd = A.reads[pd.read_id];
     const uint32_t n = rd.len, m = qd.len;
@@ -687,7 +702,8 @@ __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDes
 
     const unsigned long long tk0 = A.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
     unsigned long long tk_walk = 0, n_steps = 0, n_iters = 0;
-    for (uint32_t w = lane; w < (m + 3u) / 4u; w += WAVE) lds_read[w] = readw[w];
+    if (!read_staged)
+        for (uint32_t w = lane; w < (m + 3u) / 4u; w += WAVE) lds_read[w] = readw[w];
 
     const uint64_t cbase = A.cells_off ? A.cells_off[pd.out_id] : (uint64_t)pd.out_id * A.cell_cap;
     const uint32_t ncell = (uint32_t)po.n_cells;
@@ -747,6 +763,10 @@ __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDes
                 const uint32_t cw1 = (16u * (wlo + nb) - 1u) >> 2;
                 WAVE_SYNC();
                 if (!prestaged) {
+                    // the slice of the reference: loads issued now, stored to LDS after the re-sweep (at most 2 dwords per lane)
+                    const uint32_t rx0 = cw0 + lane, rx1 = rx0 + WAVE, rlim = (n + 3u) / 4u;
+                    const uint32_t rv0 = (rx0 <= cw1 && rx0 < rlim) ? refw[rx0] : 0u;
+                    const uint32_t rv1 = (rx1 <= cw1 && rx1 < rlim) ? refw[rx1] : 0u;
                     if (TMODE == 0) {
                         const uint32_t *__restrict__ src = dirp + s * G.strip_words + (uint64_t)wlo * R * WAVE + lane;
                         for (uint32_t x = 0; x < nb * R; ++x) lds_tile[x * WAVE + lane] = src[(uint64_t)x * WAVE];
@@ -757,7 +777,8 @@ __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDes
                         }
                         (void)replay_any<R, false>(A, pd, n, m, acgt, refw, readw, G, s, wlo, lane, lds_tile, 0, 0u, nullptr, 0u);
                     }
-                    for (uint32_t x = cw0 + lane; x <= cw1 && x < (n + 3u) / 4u; x += WAVE) lds_ref[x - cw0] = refw[x];
+                    lds_ref[lane] = rv0;
+                    if (lane + WAVE < SWMI_TB_REFWIN_WORDS) lds_ref[lane + WAVE] = rv1;
                     if (COOP) {
                         __syncthreads();                                           // (B) every wave's window is in the tile
                         if (lane == 0) shared[6u + 4u * slot] = 0u;                // request served
@@ -985,8 +1006,8 @@ __device__ __forceinline__ void traceback_entry(const TraceArgs &A, uint32_t *ld
 template <int R>
 __device__ __forceinline__ uint32_t winmax_detect(const TraceArgs &A, const PairDesc pd, PairOut &po, const uint32_t lane,
                                                   const uint32_t wave, const uint32_t n_waves, const uint32_t ccap,
-                                                  uint32_t *__restrict__ tiles, uint32_t *__restrict__ walker0_ref,
-                                                  volatile uint32_t *__restrict__ shared) {
+                                                  uint32_t *__restrict__ tiles, uint32_t *__restrict__ walker_lds,
+                                                  const uint32_t per_walker, volatile uint32_t *__restrict__ shared) {
     const SeqDesc rd = A.refs[pd.ref_id];
     const SeqDesc qd = A.reads[pd.read_id];
     const uint32_t n = rd.len, m = qd.len;
@@ -1019,8 +1040,17 @@ __device__ __forceinline__ uint32_t winmax_detect(const TraceArgs &A, const Pair
         }
         if (lane < SWMI_TB_SLOTS) shared[6u + 4u * lane] = 0u;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the cell list has left the CU before the others read it
-    } else if (pre) {
+    } else {
+        // the read's codes for the walkers: wave w fills walker w's copy, the last wave also walker 0's
+        const uint32_t *__restrict__ readw = A.seqw + qd.boff;
+        if (wave < SWMI_TB_SLOTS)
+            for (uint32_t w = lane; w < (m + 3u) / 4u; w += WAVE) walker_lds[wave * per_walker + A.lds_words + w] = readw[w];
+        if (wave == n_waves - 1u)
+            for (uint32_t w = lane; w < (m + 3u) / 4u; w += WAVE) walker_lds[A.lds_words + w] = readw[w];
+    }
+    if (wave != 0 && pre) {
         const uint32_t *__restrict__ refw = A.seqw + rd.boff;
+        uint32_t *__restrict__ walker0_ref = walker_lds + A.lds_words + A.lds_read_words;
         if (wave < nq0) {
             const uint32_t *__restrict__ readw = A.seqw + qd.boff;
             const bool acgt = rd.acgt && qd.acgt && A.match >= -128 && A.match <= 127 && A.mismatch >= -128 && A.mismatch <= 127;
@@ -1059,12 +1089,12 @@ sw_traceback_winmax_kernel(const TraceArgs A) {
     uint32_t *tiles = wm_lds + 24;
     const uint32_t R = swmi_rows_per_lane(A.reads[pd.read_id].len);
     const uint32_t ccap = A.cells_cap ? A.cells_cap[pd.out_id] : A.cell_cap;
-    uint32_t *walker0_ref = tiles + n_waves * WIN_WORDS + A.lds_words + A.lds_read_words;
+    uint32_t *walker_lds0 = tiles + n_waves * WIN_WORDS;
     uint32_t pre_wlo;
-    if (R == 1)      pre_wlo = winmax_detect<1>(A, pd, po, lane, wave, n_waves, ccap, tiles, walker0_ref, shared);
-    else if (R == 2) pre_wlo = winmax_detect<2>(A, pd, po, lane, wave, n_waves, ccap, tiles, walker0_ref, shared);
-    else if (R == 3) pre_wlo = winmax_detect<3>(A, pd, po, lane, wave, n_waves, ccap, tiles, walker0_ref, shared);
-    else             pre_wlo = winmax_detect<4>(A, pd, po, lane, wave, n_waves, ccap, tiles, walker0_ref, shared);
+    if (R == 1)      pre_wlo = winmax_detect<1>(A, pd, po, lane, wave, n_waves, ccap, tiles, walker_lds0, per_walker, shared);
+    else if (R == 2) pre_wlo = winmax_detect<2>(A, pd, po, lane, wave, n_waves, ccap, tiles, walker_lds0, per_walker, shared);
+    else if (R == 3) pre_wlo = winmax_detect<3>(A, pd, po, lane, wave, n_waves, ccap, tiles, walker_lds0, per_walker, shared);
+    else             pre_wlo = winmax_detect<4>(A, pd, po, lane, wave, n_waves, ccap, tiles, walker_lds0, per_walker, shared);
     __syncthreads();
     const uint32_t cnt = shared[0];
     if (cnt > ccap || cnt == 0u) return;
@@ -1076,19 +1106,19 @@ sw_traceback_winmax_kernel(const TraceArgs A) {
         if (wave >= nw) return;
         uint32_t *lds = tiles + n_waves * WIN_WORDS + wave * per_walker;
         uint32_t *tile = tiles + wave * WIN_WORDS;
-        if (R == 1)      traceback_pair<1, 1, false>(A, pd, po, lane, wave, nw, lds, tile, nullptr, 1u);
-        else if (R == 2) traceback_pair<2, 1, false>(A, pd, po, lane, wave, nw, lds, tile, nullptr, 1u);
-        else if (R == 3) traceback_pair<3, 1, false>(A, pd, po, lane, wave, nw, lds, tile, nullptr, 1u);
-        else             traceback_pair<4, 1, false>(A, pd, po, lane, wave, nw, lds, tile, nullptr, 1u);
+        if (R == 1)      traceback_pair<1, 1, false>(A, pd, po, lane, wave, nw, lds, tile, nullptr, 1u, 0xFFFFFFFFu, true);
+        else if (R == 2) traceback_pair<2, 1, false>(A, pd, po, lane, wave, nw, lds, tile, nullptr, 1u, 0xFFFFFFFFu, true);
+        else if (R == 3) traceback_pair<3, 1, false>(A, pd, po, lane, wave, nw, lds, tile, nullptr, 1u, 0xFFFFFFFFu, true);
+        else             traceback_pair<4, 1, false>(A, pd, po, lane, wave, nw, lds, tile, nullptr, 1u, 0xFFFFFFFFu, true);
         return;
     }
     if (wave < nw) {
         uint32_t *lds = tiles + n_waves * WIN_WORDS + wave * per_walker;
         uint32_t *tile = tiles + wave * ts * WIN_WORDS;
-        if (R == 1)      traceback_pair<1, 1, true>(A, pd, po, lane, wave, nw, lds, tile, shared, ts, nw == 1u ? pre_wlo : 0xFFFFFFFFu);
-        else if (R == 2) traceback_pair<2, 1, true>(A, pd, po, lane, wave, nw, lds, tile, shared, ts, nw == 1u ? pre_wlo : 0xFFFFFFFFu);
-        else if (R == 3) traceback_pair<3, 1, true>(A, pd, po, lane, wave, nw, lds, tile, shared, ts, nw == 1u ? pre_wlo : 0xFFFFFFFFu);
-        else             traceback_pair<4, 1, true>(A, pd, po, lane, wave, nw, lds, tile, shared, ts, nw == 1u ? pre_wlo : 0xFFFFFFFFu);
+        if (R == 1)      traceback_pair<1, 1, true>(A, pd, po, lane, wave, nw, lds, tile, shared, ts, nw == 1u ? pre_wlo : 0xFFFFFFFFu, true);
+        else if (R == 2) traceback_pair<2, 1, true>(A, pd, po, lane, wave, nw, lds, tile, shared, ts, nw == 1u ? pre_wlo : 0xFFFFFFFFu, true);
+        else if (R == 3) traceback_pair<3, 1, true>(A, pd, po, lane, wave, nw, lds, tile, shared, ts, nw == 1u ? pre_wlo : 0xFFFFFFFFu, true);
+        else             traceback_pair<4, 1, true>(A, pd, po, lane, wave, nw, lds, tile, shared, ts, nw == 1u ? pre_wlo : 0xFFFFFFFFu, true);
     } else {
         if (R == 1)      coop_helper<1>(A, pd, lane, wave, nw, ts, tiles, shared);
         else if (R == 2) coop_helper<2>(A, pd, lane, wave, nw, ts, tiles, shared);

@@ -2,9 +2,9 @@
 """Generates sparksmithwaterman_amd/csrc/swmi_cells_gen.inc: the hand-scheduled gfx950 instruction
 stream that updates the R cells a lane owns in one anti-diagonal step of the fill kernel.
 
-Per cell (ACGT variant) 9 VALU instructions:
-    v_bfe_i32     a, q, rb, 8            s(ref,read) looked up in the row's 4-entry score profile
-    v_add_u32     a, a, diag             a = NW + s
+Per cell (ACGT variant) 8 VALU instructions:
+    v_dot4_i32_i8 a, q, rb, diag         a = NW + s(ref,read): rb is the reference base one-hot (1 << 8*base), q the
+                                         row's 4 x int8 score profile, the accumulator operand the diagonal neighbour
     v_cmp_ge_i32  sI, up, left           insertion beats deletion?   (v_cmp_gt for the DistributedSW order)
     v_max_i32     t, up, left
     v_add_u32     t, gap, t              t = max(N, W) + gap
@@ -25,28 +25,34 @@ import sys
 
 INTERLEAVE = os.environ.get("SWMI_GEN_INTERLEAVE", "1") != "0"
 HAZARD = 2   # wait states: VALU writes SGPR -> VALU reads that SGPR (gfx940/gfx950)
+DOT_HAZARD = 3   # wait states: v_dot* writes a VGPR -> a different VALU opcode reads it (gfx90a+; LLVM's
+                 # DotWriteDifferentVALURead).  Inline asm is opaque to the compiler's hazard recognizer.
 
 
 class Ins:
-    def __init__(self, text, wr=(), rd=()):
-        self.text, self.wr, self.rd = text, tuple(wr), tuple(rd)
+    def __init__(self, text, wr=(), rd=(), dot=()):
+        self.text, self.wr, self.rd, self.dot = text, tuple(wr), tuple(rd), tuple(dot)
 
 
 def schedule(R, acgt, strict, dirs=True):
     ge = "v_cmp_gt_i32_e64" if strict else "v_cmp_ge_i32_e64"
     ins = []
     # phase 1: substitution scores and the diagonal candidates (all from the previous column's values)
+    def nw(k):
+        return "%[diag]" if k == 0 else f"%[i{k-1}]"
     if acgt:
+        # rb is the reference base ONE-HOT (1 << 8*base): the dot product with the row's 4 x int8 score profile
+        # picks s(ref, read), and the accumulator operand adds the diagonal neighbour in the same instruction
         for k in range(R):
-            ins.append(Ins(f"v_bfe_i32 %[a{k}], %[q{k}], %[rb], 8"))
+            ins.append(Ins(f"v_dot4_i32_i8 %[a{k}], %[q{k}], %[rb], {nw(k)}", dot=[f"a{k}"]))
     else:
         for k in range(R):
             ins.append(Ins(f"v_cmp_eq_u32_e64 %[m{k}], %[rb], %[q{k}]", wr=[f"m{k}"]))
         for k in range(R):
             ins.append(Ins(f"v_cndmask_b32_e64 %[a{k}], %[vmis], %[vmat], %[m{k}]", rd=[f"m{k}"]))
-    for k in range(R):
-        src = "%[diag]" if k == 0 else f"%[i{k-1}]"
-        ins.append(Ins(f"v_add_u32_e32 %[a{k}], %[a{k}], {src}"))
+    if not acgt:
+        for k in range(R):
+            ins.append(Ins(f"v_add_u32_e32 %[a{k}], %[a{k}], {nw(k)}"))
     # phase 2: the dependent chain down the lane's rows
     if not dirs:
         # score-only variant (checkpoint/recompute mode): 5 VALU per cell, no direction bits.  The row chain
@@ -60,8 +66,7 @@ def schedule(R, acgt, strict, dirs=True):
                           Ins(f"v_max3_i32 %[o{k}], %[a{k}], %[t], 0")])
         if INTERLEAVE and acgt:
             # ins currently holds: bfe x R, add x R.  Rebuild: row 0 lookup first, then weave.
-            look = [[Ins(f"v_bfe_i32 %[a{k}], %[q{k}], %[rb], 8"),
-                     Ins(f"v_add_u32_e32 %[a{k}], %[a{k}], " + ("%[diag]" if k == 0 else f"%[i{k-1}]"))] for k in range(R)]
+            look = [[Ins(f"v_dot4_i32_i8 %[a{k}], %[q{k}], %[rb], {nw(k)}", dot=[f"a{k}"])] for k in range(R)]
             ins = list(look[0])
             pending = [x for k in range(1, R) for x in look[k]]
             for k in range(R):
@@ -89,6 +94,7 @@ def schedule(R, acgt, strict, dirs=True):
     # hazard pass
     out = []
     last_wr = {}
+    last_dot = {}
     for i in ins:
         need = 0
         for r in i.rd:
@@ -99,6 +105,12 @@ def schedule(R, acgt, strict, dirs=True):
                 for o in out[last_wr[r] + 1:]:
                     states += o.states if hasattr(o, "states") else 1
                 need = max(need, HAZARD - states)
+        for r, at in last_dot.items():
+            if not i.dot and ("%[" + r + "]") in i.text.split(",", 1)[-1]:      # a source operand of a non-dot VALU
+                states = 0
+                for o in out[at + 1:]:
+                    states += o.states if hasattr(o, "states") else 1
+                need = max(need, DOT_HAZARD - states)
         if need > 0:
             nop = Ins(f"s_nop {need - 1}")
             nop.states = need
@@ -106,6 +118,8 @@ def schedule(R, acgt, strict, dirs=True):
         out.append(i)
         for r in i.wr:
             last_wr[r] = len(out) - 1
+        for r in i.dot:
+            last_dot[r] = len(out) - 1
     return out
 
 
