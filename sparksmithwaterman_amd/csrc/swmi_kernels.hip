@@ -251,10 +251,20 @@ __device__ __forceinline__ void fill_block16(FillState<R> &S, const uint4 w, con
         const int (&hin)[R] = (s & 1u) ? S.g : S.h;
         int (&hout)[R] = (s & 1u) ? S.h : S.g;
         const uint32_t wsel = s < 4 ? w.x : s < 8 ? w.y : s < 12 ? w.z : w.w;
-        const uint32_t code = (wsel >> (8u * (s & 3u))) & 0xFFu;          // base code of column t0+s+1 (lane 0)
-        // ACGT: codes are 0, 8, 16, 24 and travel down the lanes ONE-HOT (1 << code) so that one v_dot4_i32_i8 with
-        // the row's score profile yields NW + s(ref, read)
-        const int feed = ACGT ? (int)(1u << (code & 31u)) : (int)code;
+        // base code of column t0+s+1 (lane 0).  ACGT: codes are 0, 8, 16, 24 and travel down the lanes ONE-HOT
+        // (1 << code) so that one v_dot4_i32_i8 with the row's score profile yields NW + s(ref, read); the SDWA byte
+        // select makes extract + shift a single instruction.
+        int feed;
+        if (ACGT) {
+            switch (s & 3u) {
+            case 0:  asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(feed) : "v"(wsel), "v"(1)); break;
+            case 1:  asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(feed) : "v"(wsel), "v"(1)); break;
+            case 2:  asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(feed) : "v"(wsel), "v"(1)); break;
+            default: asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(feed) : "v"(wsel), "v"(1)); break;
+            }
+        } else {
+            feed = (int)((wsel >> (8u * (s & 3u))) & 0xFFu);
+        }
         S.rb = wave_shr1(feed, S.rb);
         int nin;
         if (MULTI) {
@@ -756,7 +766,7 @@ __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDes
                     nb = SWMI_CK_BLOCKS;
                 }
                 // COOP: the span of the first staging was already re-swept while wave 0 listed the maximum cells
-                const bool prestaged = COOP && pre_wlo == wlo && s == 0u;
+                const bool prestaged = TMODE == 1 && pre_wlo == wlo && s == 0u;
                 pre_wlo = 0xFFFFFFFFu;
                 const int clo = (int)(16u * wlo) - 63;
                 const uint32_t cw0 = clo > 0 ? (uint32_t)clo >> 2 : 0u;           // first dword of the reference window
@@ -999,10 +1009,17 @@ __device__ __forceinline__ void traceback_entry(const TraceArgs &A, uint32_t *ld
     else             traceback_pair<4, TMODE, false>(A, pd, po, lane, slot, SWMI_TB_SLOTS, tb_lds, tile, nullptr, 1u);
 }
 
-// mode 1, before the walks: wave 0 lists the maximum cells.  In the usual case -- one strip, ONE window holding the
-// pair's maximum -- the other waves meanwhile re-sweep the windows below it (and copy the slice of the reference), so
-// that the span a single alignment's walk starts in is complete when the cell list is.  Returns the first block of
-// that span, or ~0 when nothing was pre-staged.  shared[0] receives the number of cells.
+// mode 1, before the walks: the pair's maximum cells are listed, and the first span of each walk is prepared at the
+// same time.  The sweep left one maximum per checkpoint window; a window whose maximum equals the pair's is a candidate.
+//   * one candidate (the usual case): wave 0 re-sweeps it with the cell test on, the other waves re-sweep the windows
+//     below it, so the span a single alignment's walk starts in is complete when the cell list is;
+//   * 2..4 candidates: wave w re-sweeps candidate w (cells into its own quarter of the pair's cell list), the remaining
+//     waves the windows below their team's candidate.  If every candidate holds exactly ONE maximum cell the quarters
+//     are compacted and walker w starts in its own window; otherwise the generic path below runs;
+//   * generic: wave 0 re-sweeps all candidates one after the other (detect_cells).
+// On return the workgroup has passed a barrier, shared[0] = number of cells, shared[3] = 1 if every walker's first span
+// is staged; the return value is this wave's first staged block (~0: none).  shared[24..27] / [28..31]: per candidate
+// cell count / first staged block.
 template <int R>
 __device__ __forceinline__ uint32_t winmax_detect(const TraceArgs &A, const PairDesc pd, PairOut &po, const uint32_t lane,
                                                   const uint32_t wave, const uint32_t n_waves, const uint32_t ccap,
@@ -1011,25 +1028,33 @@ __device__ __forceinline__ uint32_t winmax_detect(const TraceArgs &A, const Pair
     const SeqDesc rd = A.refs[pd.ref_id];
     const SeqDesc qd = A.reads[pd.read_id];
     const uint32_t n = rd.len, m = qd.len;
+    const uint32_t *__restrict__ refw = A.seqw + rd.boff;
+    const uint32_t *__restrict__ readw = A.seqw + qd.boff;
+    const bool acgt = rd.acgt && qd.acgt && A.match >= -128 && A.match <= 127 && A.mismatch >= -128 && A.mismatch <= 127;
     const StripGeom G = strip_geom<R>(m, n, 1u);
-    uint32_t ncand = 0, gfirst = 0;
+    constexpr uint32_t WIN_WORDS = SWMI_CK_BLOCKS * SWMI_RMAX * WAVE;
+    uint32_t ncand = 0, gc[SWMI_TB_SLOTS] = {0u, 0u, 0u, 0u};
     if (G.n_strips == 1u) {
         const uint32_t *__restrict__ wm = A.dir + pd.dir_off + G.wmax_off;
         for (uint32_t g0 = 0; g0 < G.n_ck; g0 += WAVE) {
             const uint32_t g = g0 + lane;
             const int wv = g < G.n_ck ? (int)wm[g] : -1;
-            const uint64_t cand = BALLOT(wv == po.score);
-            if (cand) {
-                if (!ncand) gfirst = g0 + (uint32_t)__builtin_ctzll(cand);
-                ncand += (uint32_t)__builtin_popcountll(cand);
+            uint64_t cand = BALLOT(wv == po.score);
+            while (cand) {
+                const uint32_t gg = g0 + (uint32_t)__builtin_ctzll(cand);
+                cand &= cand - 1ull;
+                if (ncand == 0u) gc[0] = gg; else if (ncand == 1u) gc[1] = gg; else if (ncand == 2u) gc[2] = gg; else if (ncand == 3u) gc[3] = gg;
+                ++ncand;
             }
         }
     }
-    const bool pre = ncand == 1u;
-    const uint32_t nq0 = gfirst + 1u < n_waves ? gfirst + 1u : n_waves;           // windows of the span that ends with window gfirst
-    const uint32_t wlo0 = (gfirst + 1u - nq0) * SWMI_CK_BLOCKS;
-    if (wave == 0) {
-        const uint32_t cnt = detect_cells<R>(A, pd, po, lane, pre ? tiles + (nq0 - 1u) * SWMI_CK_BLOCKS * R * WAVE : tiles);
+    auto stage_ref = [&](uint32_t *__restrict__ dst, uint32_t wlo, uint32_t nwin) {
+        const int clo = (int)(16u * wlo) - 63;
+        const uint32_t cw0 = clo > 0 ? (uint32_t)clo >> 2 : 0u;
+        const uint32_t cw1 = (16u * (wlo + nwin * SWMI_CK_BLOCKS) - 1u) >> 2;
+        for (uint32_t x = cw0 + lane; x <= cw1 && x < (n + 3u) / 4u; x += WAVE) dst[x - cw0] = refw[x];
+    };
+    auto publish = [&](uint32_t cnt, uint32_t staged) {      // wave 0, after the cells are listed
         if (lane == 0) {
             po.n_cells = cnt;
             if (cnt > ccap) po.flags |= SWMI_F_CELL_OVF;
@@ -1037,34 +1062,75 @@ __device__ __forceinline__ uint32_t winmax_detect(const TraceArgs &A, const Pair
             if (A.out_host) A.out_host[pd.out_id] = po;
             shared[0] = cnt;
             shared[1] = 0u;
+            shared[3] = staged;
         }
         if (lane < SWMI_TB_SLOTS) shared[6u + 4u * lane] = 0u;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the cell list has left the CU before the others read it
+    };
+    const uint64_t cbase = A.cells_off ? A.cells_off[pd.out_id] : (uint64_t)pd.out_id * A.cell_cap;
+    uint2 *__restrict__ cells = const_cast<uint2 *>(A.cells) + cbase;
+
+    const uint32_t seg = ccap / SWMI_TB_SLOTS;
+    if (ncand >= 2u && ncand <= SWMI_TB_SLOTS && ncand <= n_waves && seg >= 1u) {
+        const uint32_t nw = ncand, ts = n_waves / nw;
+        if (wave < nw) {
+            const uint32_t g = wave == 0u ? gc[0] : wave == 1u ? gc[1] : wave == 2u ? gc[2] : gc[3];
+            const uint32_t nq0 = g + 1u < ts ? g + 1u : ts;
+            const uint32_t wlo0 = (g + 1u - nq0) * SWMI_CK_BLOCKS;
+            uint32_t *my = walker_lds + wave * per_walker;
+            for (uint32_t w = lane; w < (m + 3u) / 4u; w += WAVE) my[A.lds_words + w] = readw[w];
+            stage_ref(my + A.lds_words + A.lds_read_words, wlo0, nq0);
+            const uint32_t c = replay_any<R, true>(A, pd, n, m, acgt, refw, readw, G, 0u, g * SWMI_CK_BLOCKS, lane,
+                                                   tiles + wave * ts * WIN_WORDS + (nq0 - 1u) * SWMI_CK_BLOCKS * R * WAVE,
+                                                   po.score, 0u, cells + wave * seg, seg);
+            if (lane == 0) { shared[24u + wave] = c; shared[28u + wave] = wlo0; }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            const uint32_t team = (wave - nw) % nw, q = 1u + (wave - nw) / nw;
+            const uint32_t g = team == 0u ? gc[0] : team == 1u ? gc[1] : team == 2u ? gc[2] : gc[3];
+            const uint32_t nq0 = g + 1u < ts ? g + 1u : ts;
+            if (q < nq0)
+                (void)replay_any<R, false>(A, pd, n, m, acgt, refw, readw, G, 0u, (g - q) * SWMI_CK_BLOCKS, lane,
+                                           tiles + team * ts * WIN_WORDS + (nq0 - 1u - q) * SWMI_CK_BLOCKS * R * WAVE,
+                                           0, 0u, nullptr, 0u);
+        }
+        __syncthreads();
+        bool one_each = true;
+        for (uint32_t w = 0; w < nw; ++w) one_each = one_each && shared[24u + w] == 1u;
+        if (one_each) {
+            if (wave == 0) {
+                uint2 c = make_uint2(0, 0);
+                if (lane < nw) { c.x = ld_l2(&cells[lane * seg].x); c.y = ld_l2(&cells[lane * seg].y); }
+                if (lane < nw) cells[lane] = c;
+                publish(nw, 1u);
+            }
+            __syncthreads();
+            return wave < nw ? shared[28u + wave] : 0xFFFFFFFFu;
+        }
+        __syncthreads();                                     // everybody has read the counts before wave 0 reuses shared[]
+    }
+
+    const bool pre = ncand == 1u;
+    const uint32_t nq0 = gc[0] + 1u < n_waves ? gc[0] + 1u : n_waves;             // windows of the span that ends with window gc[0]
+    const uint32_t wlo0 = (gc[0] + 1u - nq0) * SWMI_CK_BLOCKS;
+    if (wave == 0) {
+        const uint32_t cnt = detect_cells<R>(A, pd, po, lane, pre ? tiles + (nq0 - 1u) * SWMI_CK_BLOCKS * R * WAVE : tiles);
+        publish(cnt, (pre && cnt == 1u) ? 1u : 0u);
     } else {
         // the read's codes for the walkers: wave w fills walker w's copy, the last wave also walker 0's
-        const uint32_t *__restrict__ readw = A.seqw + qd.boff;
         if (wave < SWMI_TB_SLOTS)
             for (uint32_t w = lane; w < (m + 3u) / 4u; w += WAVE) walker_lds[wave * per_walker + A.lds_words + w] = readw[w];
         if (wave == n_waves - 1u)
             for (uint32_t w = lane; w < (m + 3u) / 4u; w += WAVE) walker_lds[A.lds_words + w] = readw[w];
-    }
-    if (wave != 0 && pre) {
-        const uint32_t *__restrict__ refw = A.seqw + rd.boff;
-        uint32_t *__restrict__ walker0_ref = walker_lds + A.lds_words + A.lds_read_words;
-        if (wave < nq0) {
-            const uint32_t *__restrict__ readw = A.seqw + qd.boff;
-            const bool acgt = rd.acgt && qd.acgt && A.match >= -128 && A.match <= 127 && A.mismatch >= -128 && A.mismatch <= 127;
-            (void)replay_any<R, false>(A, pd, n, m, acgt, refw, readw, G, 0u, wlo0 + (wave - 1u) * SWMI_CK_BLOCKS, lane,
-                                       tiles + (wave - 1u) * SWMI_CK_BLOCKS * R * WAVE, 0, 0u, nullptr, 0u);
-        }
-        if (wave == n_waves - 1u) {                          // the wave least likely to have a window to re-sweep
-            const int clo = (int)(16u * wlo0) - 63;
-            const uint32_t cw0 = clo > 0 ? (uint32_t)clo >> 2 : 0u;
-            const uint32_t cw1 = (16u * (wlo0 + nq0 * SWMI_CK_BLOCKS) - 1u) >> 2;
-            for (uint32_t x = cw0 + lane; x <= cw1 && x < (n + 3u) / 4u; x += WAVE) walker0_ref[x - cw0] = refw[x];
+        if (pre) {
+            if (wave < nq0)
+                (void)replay_any<R, false>(A, pd, n, m, acgt, refw, readw, G, 0u, wlo0 + (wave - 1u) * SWMI_CK_BLOCKS, lane,
+                                           tiles + (wave - 1u) * SWMI_CK_BLOCKS * R * WAVE, 0, 0u, nullptr, 0u);
+            if (wave == n_waves - 1u) stage_ref(walker_lds + A.lds_words + A.lds_read_words, wlo0, nq0);
         }
     }
-    return pre ? wlo0 : 0xFFFFFFFFu;
+    __syncthreads();
+    return (pre && wave == 0) ? wlo0 : 0xFFFFFFFFu;
 }
 
 // mode 1: one workgroup of SWMI_TB_WAVES waves = ONE pair.  Wave 0 first lists the maximum cells (detect_cells),
@@ -1081,12 +1147,12 @@ sw_traceback_winmax_kernel(const TraceArgs A) {
         if (A.out_host && wave == 0 && lane == 0) A.out_host[pd.out_id] = po;
         return;
     }
-    // LDS: [24 shared words][tiles: one window per wave][per walker: ops staging, read codes, reference window]
+    // LDS: [32 shared words][tiles: one window per wave][per walker: ops staging, read codes, reference window]
     const uint32_t n_waves = blockDim.x >> 6;
     const uint32_t per_walker = A.lds_words + A.lds_read_words + SWMI_TB_REFWIN_WORDS;
     constexpr uint32_t WIN_WORDS = SWMI_CK_BLOCKS * SWMI_RMAX * WAVE;
     uint32_t *shared = wm_lds;
-    uint32_t *tiles = wm_lds + 24;
+    uint32_t *tiles = wm_lds + 32;
     const uint32_t R = swmi_rows_per_lane(A.reads[pd.read_id].len);
     const uint32_t ccap = A.cells_cap ? A.cells_cap[pd.out_id] : A.cell_cap;
     uint32_t *walker_lds0 = tiles + n_waves * WIN_WORDS;
@@ -1095,8 +1161,8 @@ sw_traceback_winmax_kernel(const TraceArgs A) {
     else if (R == 2) pre_wlo = winmax_detect<2>(A, pd, po, lane, wave, n_waves, ccap, tiles, walker_lds0, per_walker, shared);
     else if (R == 3) pre_wlo = winmax_detect<3>(A, pd, po, lane, wave, n_waves, ccap, tiles, walker_lds0, per_walker, shared);
     else             pre_wlo = winmax_detect<4>(A, pd, po, lane, wave, n_waves, ccap, tiles, walker_lds0, per_walker, shared);
-    __syncthreads();
-    const uint32_t cnt = shared[0];
+    const uint32_t cnt = shared[0];                                    // (winmax_detect ends with a barrier)
+    if (shared[3] != 1u) pre_wlo = 0xFFFFFFFFu;                        // no staged first spans
     if (cnt > ccap || cnt == 0u) return;
     po.n_cells = cnt;
     const uint32_t nw = cnt < SWMI_TB_SLOTS ? cnt : SWMI_TB_SLOTS;     // walkers = teams
@@ -1106,19 +1172,19 @@ sw_traceback_winmax_kernel(const TraceArgs A) {
         if (wave >= nw) return;
         uint32_t *lds = tiles + n_waves * WIN_WORDS + wave * per_walker;
         uint32_t *tile = tiles + wave * WIN_WORDS;
-        if (R == 1)      traceback_pair<1, 1, false>(A, pd, po, lane, wave, nw, lds, tile, nullptr, 1u, 0xFFFFFFFFu, true);
-        else if (R == 2) traceback_pair<2, 1, false>(A, pd, po, lane, wave, nw, lds, tile, nullptr, 1u, 0xFFFFFFFFu, true);
-        else if (R == 3) traceback_pair<3, 1, false>(A, pd, po, lane, wave, nw, lds, tile, nullptr, 1u, 0xFFFFFFFFu, true);
-        else             traceback_pair<4, 1, false>(A, pd, po, lane, wave, nw, lds, tile, nullptr, 1u, 0xFFFFFFFFu, true);
+        if (R == 1)      traceback_pair<1, 1, false>(A, pd, po, lane, wave, nw, lds, tile, nullptr, 1u, pre_wlo, true);
+        else if (R == 2) traceback_pair<2, 1, false>(A, pd, po, lane, wave, nw, lds, tile, nullptr, 1u, pre_wlo, true);
+        else if (R == 3) traceback_pair<3, 1, false>(A, pd, po, lane, wave, nw, lds, tile, nullptr, 1u, pre_wlo, true);
+        else             traceback_pair<4, 1, false>(A, pd, po, lane, wave, nw, lds, tile, nullptr, 1u, pre_wlo, true);
         return;
     }
     if (wave < nw) {
         uint32_t *lds = tiles + n_waves * WIN_WORDS + wave * per_walker;
         uint32_t *tile = tiles + wave * ts * WIN_WORDS;
-        if (R == 1)      traceback_pair<1, 1, true>(A, pd, po, lane, wave, nw, lds, tile, shared, ts, nw == 1u ? pre_wlo : 0xFFFFFFFFu, true);
-        else if (R == 2) traceback_pair<2, 1, true>(A, pd, po, lane, wave, nw, lds, tile, shared, ts, nw == 1u ? pre_wlo : 0xFFFFFFFFu, true);
-        else if (R == 3) traceback_pair<3, 1, true>(A, pd, po, lane, wave, nw, lds, tile, shared, ts, nw == 1u ? pre_wlo : 0xFFFFFFFFu, true);
-        else             traceback_pair<4, 1, true>(A, pd, po, lane, wave, nw, lds, tile, shared, ts, nw == 1u ? pre_wlo : 0xFFFFFFFFu, true);
+        if (R == 1)      traceback_pair<1, 1, true>(A, pd, po, lane, wave, nw, lds, tile, shared, ts, pre_wlo, true);
+        else if (R == 2) traceback_pair<2, 1, true>(A, pd, po, lane, wave, nw, lds, tile, shared, ts, pre_wlo, true);
+        else if (R == 3) traceback_pair<3, 1, true>(A, pd, po, lane, wave, nw, lds, tile, shared, ts, pre_wlo, true);
+        else             traceback_pair<4, 1, true>(A, pd, po, lane, wave, nw, lds, tile, shared, ts, pre_wlo, true);
     } else {
         if (R == 1)      coop_helper<1>(A, pd, lane, wave, nw, ts, tiles, shared);
         else if (R == 2) coop_helper<2>(A, pd, lane, wave, nw, ts, tiles, shared);
@@ -1161,7 +1227,7 @@ extern "C" hipError_t swmi_launch_traceback(const TraceArgs *a, hipStream_t st) 
         // at once (4 waves per SIMD at this kernel's register count), else 4
         static int forced = getenv("SWMI_TB_WAVES") ? atoi(getenv("SWMI_TB_WAVES")) : 0;
         const uint32_t n_waves = forced ? (uint32_t)forced : (a->n_pairs <= 512u ? SWMI_TB_WAVES : 4u);
-        const size_t words = 24 + (size_t)n_waves * SWMI_CK_BLOCKS * SWMI_RMAX * WAVE +
+        const size_t words = 32 + (size_t)n_waves * SWMI_CK_BLOCKS * SWMI_RMAX * WAVE +
                              (size_t)SWMI_TB_SLOTS * ((size_t)a->lds_words + a->lds_read_words + SWMI_TB_REFWIN_WORDS);
         hipLaunchKernelGGL(sw_traceback_winmax_kernel, dim3(a->n_pairs), dim3(WAVE * n_waves), words * sizeof(uint32_t), st, *a);
     } else {

@@ -41,6 +41,29 @@ __global__ void __launch_bounds__(256) k(int *out, int iters, long long *cyc) {
                 "v_addc_co_u32 %0, vcc, %0, %0, s[12:13]\n")
                 : "+v"(acc), "+v"(a), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "v"(b) : "vcc", "s10", "s11", "s12", "s13");
         }
+        if (V == 8) { asm volatile(REP16("v_dot4_i32_i8 %0, %4, %5, %0\n v_dot4_i32_i8 %1, %4, %5, %1\n v_dot4_i32_i8 %2, %4, %5, %2\n v_dot4_i32_i8 %3, %4, %5, %3\n")
+                                   : "+v"(a), "+v"(c), "+v"(d), "+v"(e) : "v"(b), "v"(f)); }
+        if (V == 9) {      // score-only cell, dot4 form (3 rows interleaved as in the generated stream)
+            asm volatile(REP16(
+                "v_dot4_i32_i8 %0, %4, %5, %1\n"
+                "v_max_i32 %3, %1, %2\n"
+                "v_add_u32 %3, %3, %6\n"
+                "s_nop 0\n"
+                "v_max3_i32 %2, %0, %3, 0\n")
+                : "+v"(a), "+v"(c), "+v"(d), "+v"(e) : "v"(b), "v"(f), "v"(g));
+        }
+        if (V == 10) {     // score-only cell, bfe + add form
+            asm volatile(REP16(
+                "v_bfe_i32 %0, %4, %5, 8\n"
+                "v_add_u32 %0, %0, %1\n"
+                "v_max_i32 %3, %1, %2\n"
+                "v_add_u32 %3, %3, %6\n"
+                "v_max3_i32 %2, %0, %3, 0\n")
+                : "+v"(a), "+v"(c), "+v"(d), "+v"(e) : "v"(b), "v"(f), "v"(g));
+        }
+        if (V == 11) { int sa = it; asm volatile(REP64("s_add_u32 %0, %0, 3\n") : "+s"(sa)); a += sa; }
+        if (V == 12) { int sa = it; asm volatile(REP16("s_add_u32 %0, %0, 3\n v_add_u32 %1, %1, %2\n s_add_u32 %0, %0, 5\n v_add_u32 %1, %1, %2\n") : "+s"(sa), "+v"(a) : "v"(b)); a += sa; }
+        if (V == 13) { int sa = it; asm volatile(REP16("s_cmp_lg_u32 %0, 77\n s_cbranch_scc0 1f\n1:\n v_add_u32 %1, %1, %2\n s_add_u32 %0, %0, 5\n") : "+s"(sa), "+v"(a) : "v"(b) : "scc"); a += sa; }
     }
     long long t1 = __builtin_amdgcn_s_memtime();
     out[blockIdx.x * blockDim.x + threadIdx.x] = a + c + d + e + (int)acc + f + g + h;
@@ -91,5 +114,11 @@ int main() {
     run<5>("v_bfe_i32 dep", 64, dout, dcyc);
     run<6>("cmp,s_nop1,addc,add", 64, dout, dcyc);
     run<7>("DP-cell mix (10 instr)", 160, dout, dcyc);
+    run<8>("v_dot4_i32_i8 4 chains", 64, dout, dcyc);
+    run<9>("cell dot4 (4 VALU + nop)", 80, dout, dcyc);
+    run<10>("cell bfe+add (5 VALU)", 80, dout, dcyc);
+    run<11>("s_add dep chain", 64, dout, dcyc);
+    run<12>("s_add / v_add alternating", 64, dout, dcyc);
+    run<13>("s_cmp, branch(not taken), v_add, s_add", 64, dout, dcyc);
     return 0;
 }
