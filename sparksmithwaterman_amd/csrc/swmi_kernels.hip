@@ -631,12 +631,22 @@ __device__ __forceinline__ uint32_t replay_dispatch(const TraceArgs &A, const Pa
     }
 }
 
-// replays with or without the multi-strip seam handling (only R == SWMI_RMAX reads can span several strips)
-template <int R, bool DETECT>
+// true for the pairs the full-featured mode-1 traceback handles: pure ACGT with int8 scores, the serial tie order, one strip
+__device__ __forceinline__ bool swmi_common_pair(const TraceArgs &A, const SeqDesc rd, const SeqDesc qd) {
+    return rd.acgt && qd.acgt && A.match >= -128 && A.match <= 127 && A.mismatch >= -128 && A.mismatch <= 127 &&
+           !A.strict && qd.len <= WAVE * SWMI_RMAX;
+}
+
+// re-sweeps one window.  FULL: any variant (byte alphabet, DistributedSW tie order, several strips); otherwise only the
+// common one -- the call sites of the team code are many, and every variant inlined at each of them is what made this
+// file take six minutes to compile.
+template <int R, bool DETECT, bool FULL = true>
 __device__ __forceinline__ uint32_t replay_any(const TraceArgs &A, const PairDesc pd, uint32_t n, uint32_t m, bool acgt,
                                                const uint32_t *__restrict__ refw, const uint32_t *__restrict__ readw,
                                                const StripGeom G, uint32_t s, uint32_t wlo, uint32_t lane, uint32_t *lds_tile,
                                                int maxv, uint32_t cnt_in, uint2 *__restrict__ cells, uint32_t ccap) {
+    if constexpr (!FULL)
+        return replay_window<R, true, false, false, DETECT>(A, pd, n, m, refw, readw, G, s, wlo, lane, lds_tile, maxv, cnt_in, cells, ccap);
     if constexpr (R == SWMI_RMAX) {
         if (m > WAVE * SWMI_RMAX)
             return replay_dispatch<R, true, DETECT>(A, pd, n, m, acgt, refw, readw, G, s, wlo, lane, lds_tile, maxv, cnt_in, cells, ccap);
@@ -646,7 +656,7 @@ __device__ __forceinline__ uint32_t replay_any(const TraceArgs &A, const PairDes
 
 // mode 1: list the pair's maximum cells.  The sweep left one maximum per checkpoint window; every window whose
 // maximum equals the pair's is re-swept once with the cell test switched on.
-template <int R>
+template <int R, bool FULL = true>
 __device__ __forceinline__ uint32_t detect_cells(const TraceArgs &A, const PairDesc pd, const PairOut po,
                                                  const uint32_t lane, uint32_t *__restrict__ lds_tile) {
     const SeqDesc rd = A.refs[pd.ref_id];
@@ -669,7 +679,7 @@ __device__ __forceinline__ uint32_t detect_cells(const TraceArgs &A, const PairD
             while (cand) {
                 const uint32_t gg = g0 + (uint32_t)__builtin_ctzll(cand);
                 cand &= cand - 1ull;
-                cnt = replay_any<R, true>(A, pd, n, m, acgt, refw, readw, G, s, gg * SWMI_CK_BLOCKS, lane, lds_tile,
+                cnt = replay_any<R, true, FULL>(A, pd, n, m, acgt, refw, readw, G, s, gg * SWMI_CK_BLOCKS, lane, lds_tile,
                                           po.score, cnt, cells, ccap);
             }
         }
@@ -683,7 +693,7 @@ __device__ __forceinline__ uint32_t detect_cells(const TraceArgs &A, const PairD
 // and the walker then crosses the whole 32*ts-step span without stopping.  All waves of the workgroup move in
 // rounds delimited by two barriers: (A) requests published, (B) tiles complete.
 // shared[]: [0] number of maximum cells, [1] walkers finished, [4+4t ..] team t's request {strip, first block, windows}.
-template <int R, int TMODE, bool COOP>
+template <int R, int TMODE, bool COOP, bool FULL = true>
 __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDesc pd, const PairOut po,
                                                const uint32_t lane, const uint32_t slot, const uint32_t nslots,
                                                uint32_t *__restrict__ lds, uint32_t *__restrict__ lds_tile,
@@ -785,7 +795,7 @@ __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDes
                             if (lane == 0) { shared[4u + 4u * slot] = s; shared[5u + 4u * slot] = wlo; shared[6u + 4u * slot] = nb / SWMI_CK_BLOCKS; }
                             __syncthreads();                                       // (A) request visible to the helpers
                         }
-                        (void)replay_any<R, false>(A, pd, n, m, acgt, refw, readw, G, s, wlo, lane, lds_tile, 0, 0u, nullptr, 0u);
+                        (void)replay_any<R, false, FULL>(A, pd, n, m, acgt, refw, readw, G, s, wlo, lane, lds_tile, 0, 0u, nullptr, 0u);
                     }
                     lds_ref[lane] = rv0;
                     if (lane + WAVE < SWMI_TB_REFWIN_WORDS) lds_ref[lane + WAVE] = rv1;
@@ -978,7 +988,7 @@ __device__ __forceinline__ void coop_helper(const TraceArgs &A, const PairDesc p
         if (shared[1] == nw) break;
         const uint32_t s = shared[4u + 4u * team], wlo = shared[5u + 4u * team], nq = shared[6u + 4u * team];
         if (q < ts && q < nq)
-            (void)replay_any<R, false>(A, pd, n, m, acgt, refw, readw, G, s, wlo + q * SWMI_CK_BLOCKS, lane,
+            (void)replay_any<R, false, false>(A, pd, n, m, acgt, refw, readw, G, s, wlo + q * SWMI_CK_BLOCKS, lane,
                                        tiles + team * ts * (SWMI_CK_BLOCKS * SWMI_RMAX * WAVE) + q * SWMI_CK_BLOCKS * R * WAVE,
                                        0, 0u, nullptr, 0u);
         __syncthreads();                                                           // (B)
@@ -1080,7 +1090,7 @@ __device__ __forceinline__ uint32_t winmax_detect(const TraceArgs &A, const Pair
             uint32_t *my = walker_lds + wave * per_walker;
             for (uint32_t w = lane; w < (m + 3u) / 4u; w += WAVE) my[A.lds_words + w] = readw[w];
             stage_ref(my + A.lds_words + A.lds_read_words, wlo0, nq0);
-            const uint32_t c = replay_any<R, true>(A, pd, n, m, acgt, refw, readw, G, 0u, g * SWMI_CK_BLOCKS, lane,
+            const uint32_t c = replay_any<R, true, false>(A, pd, n, m, acgt, refw, readw, G, 0u, g * SWMI_CK_BLOCKS, lane,
                                                    tiles + wave * ts * WIN_WORDS + (nq0 - 1u) * SWMI_CK_BLOCKS * R * WAVE,
                                                    po.score, 0u, cells + wave * seg, seg);
             if (lane == 0) { shared[24u + wave] = c; shared[28u + wave] = wlo0; }
@@ -1090,7 +1100,7 @@ __device__ __forceinline__ uint32_t winmax_detect(const TraceArgs &A, const Pair
             const uint32_t g = team == 0u ? gc[0] : team == 1u ? gc[1] : team == 2u ? gc[2] : gc[3];
             const uint32_t nq0 = g + 1u < ts ? g + 1u : ts;
             if (q < nq0)
-                (void)replay_any<R, false>(A, pd, n, m, acgt, refw, readw, G, 0u, (g - q) * SWMI_CK_BLOCKS, lane,
+                (void)replay_any<R, false, false>(A, pd, n, m, acgt, refw, readw, G, 0u, (g - q) * SWMI_CK_BLOCKS, lane,
                                            tiles + team * ts * WIN_WORDS + (nq0 - 1u - q) * SWMI_CK_BLOCKS * R * WAVE,
                                            0, 0u, nullptr, 0u);
         }
@@ -1114,7 +1124,7 @@ __device__ __forceinline__ uint32_t winmax_detect(const TraceArgs &A, const Pair
     const uint32_t nq0 = gc[0] + 1u < n_waves ? gc[0] + 1u : n_waves;             // windows of the span that ends with window gc[0]
     const uint32_t wlo0 = (gc[0] + 1u - nq0) * SWMI_CK_BLOCKS;
     if (wave == 0) {
-        const uint32_t cnt = detect_cells<R>(A, pd, po, lane, pre ? tiles + (nq0 - 1u) * SWMI_CK_BLOCKS * R * WAVE : tiles);
+        const uint32_t cnt = detect_cells<R, false>(A, pd, po, lane, pre ? tiles + (nq0 - 1u) * SWMI_CK_BLOCKS * R * WAVE : tiles);
         publish(cnt, (pre && cnt == 1u) ? 1u : 0u);
     } else {
         // the read's codes for the walkers: wave w fills walker w's copy, the last wave also walker 0's
@@ -1124,7 +1134,7 @@ __device__ __forceinline__ uint32_t winmax_detect(const TraceArgs &A, const Pair
             for (uint32_t w = lane; w < (m + 3u) / 4u; w += WAVE) walker_lds[A.lds_words + w] = readw[w];
         if (pre) {
             if (wave < nq0)
-                (void)replay_any<R, false>(A, pd, n, m, acgt, refw, readw, G, 0u, wlo0 + (wave - 1u) * SWMI_CK_BLOCKS, lane,
+                (void)replay_any<R, false, false>(A, pd, n, m, acgt, refw, readw, G, 0u, wlo0 + (wave - 1u) * SWMI_CK_BLOCKS, lane,
                                            tiles + (wave - 1u) * SWMI_CK_BLOCKS * R * WAVE, 0, 0u, nullptr, 0u);
             if (wave == n_waves - 1u) stage_ref(walker_lds + A.lds_words + A.lds_read_words, wlo0, nq0);
         }
@@ -1156,6 +1166,37 @@ sw_traceback_winmax_kernel(const TraceArgs A) {
     const uint32_t R = swmi_rows_per_lane(A.reads[pd.read_id].len);
     const uint32_t ccap = A.cells_cap ? A.cells_cap[pd.out_id] : A.cell_cap;
     uint32_t *walker_lds0 = tiles + n_waves * WIN_WORDS;
+    if (!swmi_common_pair(A, A.refs[pd.ref_id], A.reads[pd.read_id])) {
+        // a byte alphabet, the DistributedSW tie order or a read of several strips: the plain scheme -- wave 0 lists the
+        // cells, then up to four independent walkers, one window at a time -- with every kernel variant available
+        if (wave == 0) {
+            uint32_t c;
+            if (R == 1)      c = detect_cells<1>(A, pd, po, lane, tiles);
+            else if (R == 2) c = detect_cells<2>(A, pd, po, lane, tiles);
+            else if (R == 3) c = detect_cells<3>(A, pd, po, lane, tiles);
+            else             c = detect_cells<4>(A, pd, po, lane, tiles);
+            if (lane == 0) {
+                po.n_cells = c;
+                if (c > ccap) po.flags |= SWMI_F_CELL_OVF;
+                A.out[pd.out_id] = po;
+                if (A.out_host) A.out_host[pd.out_id] = po;
+                shared[0] = c;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the cell list has left the CU before the others read it
+        }
+        __syncthreads();
+        const uint32_t c = shared[0];
+        if (c > ccap || wave >= c || wave >= SWMI_TB_SLOTS) return;
+        po.n_cells = c;
+        const uint32_t nwr = c < SWMI_TB_SLOTS ? c : SWMI_TB_SLOTS;
+        uint32_t *lds = walker_lds0 + wave * per_walker;
+        uint32_t *tile = tiles + wave * WIN_WORDS;
+        if (R == 1)      traceback_pair<1, 1, false>(A, pd, po, lane, wave, nwr, lds, tile, nullptr, 1u);
+        else if (R == 2) traceback_pair<2, 1, false>(A, pd, po, lane, wave, nwr, lds, tile, nullptr, 1u);
+        else if (R == 3) traceback_pair<3, 1, false>(A, pd, po, lane, wave, nwr, lds, tile, nullptr, 1u);
+        else             traceback_pair<4, 1, false>(A, pd, po, lane, wave, nwr, lds, tile, nullptr, 1u);
+        return;
+    }
     uint32_t pre_wlo;
     if (R == 1)      pre_wlo = winmax_detect<1>(A, pd, po, lane, wave, n_waves, ccap, tiles, walker_lds0, per_walker, shared);
     else if (R == 2) pre_wlo = winmax_detect<2>(A, pd, po, lane, wave, n_waves, ccap, tiles, walker_lds0, per_walker, shared);
@@ -1172,19 +1213,19 @@ sw_traceback_winmax_kernel(const TraceArgs A) {
         if (wave >= nw) return;
         uint32_t *lds = tiles + n_waves * WIN_WORDS + wave * per_walker;
         uint32_t *tile = tiles + wave * WIN_WORDS;
-        if (R == 1)      traceback_pair<1, 1, false>(A, pd, po, lane, wave, nw, lds, tile, nullptr, 1u, pre_wlo, true);
-        else if (R == 2) traceback_pair<2, 1, false>(A, pd, po, lane, wave, nw, lds, tile, nullptr, 1u, pre_wlo, true);
-        else if (R == 3) traceback_pair<3, 1, false>(A, pd, po, lane, wave, nw, lds, tile, nullptr, 1u, pre_wlo, true);
-        else             traceback_pair<4, 1, false>(A, pd, po, lane, wave, nw, lds, tile, nullptr, 1u, pre_wlo, true);
+        if (R == 1)      traceback_pair<1, 1, false, false>(A, pd, po, lane, wave, nw, lds, tile, nullptr, 1u, pre_wlo, true);
+        else if (R == 2) traceback_pair<2, 1, false, false>(A, pd, po, lane, wave, nw, lds, tile, nullptr, 1u, pre_wlo, true);
+        else if (R == 3) traceback_pair<3, 1, false, false>(A, pd, po, lane, wave, nw, lds, tile, nullptr, 1u, pre_wlo, true);
+        else             traceback_pair<4, 1, false, false>(A, pd, po, lane, wave, nw, lds, tile, nullptr, 1u, pre_wlo, true);
         return;
     }
     if (wave < nw) {
         uint32_t *lds = tiles + n_waves * WIN_WORDS + wave * per_walker;
         uint32_t *tile = tiles + wave * ts * WIN_WORDS;
-        if (R == 1)      traceback_pair<1, 1, true>(A, pd, po, lane, wave, nw, lds, tile, shared, ts, pre_wlo, true);
-        else if (R == 2) traceback_pair<2, 1, true>(A, pd, po, lane, wave, nw, lds, tile, shared, ts, pre_wlo, true);
-        else if (R == 3) traceback_pair<3, 1, true>(A, pd, po, lane, wave, nw, lds, tile, shared, ts, pre_wlo, true);
-        else             traceback_pair<4, 1, true>(A, pd, po, lane, wave, nw, lds, tile, shared, ts, pre_wlo, true);
+        if (R == 1)      traceback_pair<1, 1, true, false>(A, pd, po, lane, wave, nw, lds, tile, shared, ts, pre_wlo, true);
+        else if (R == 2) traceback_pair<2, 1, true, false>(A, pd, po, lane, wave, nw, lds, tile, shared, ts, pre_wlo, true);
+        else if (R == 3) traceback_pair<3, 1, true, false>(A, pd, po, lane, wave, nw, lds, tile, shared, ts, pre_wlo, true);
+        else             traceback_pair<4, 1, true, false>(A, pd, po, lane, wave, nw, lds, tile, shared, ts, pre_wlo, true);
     } else {
         if (R == 1)      coop_helper<1>(A, pd, lane, wave, nw, ts, tiles, shared);
         else if (R == 2) coop_helper<2>(A, pd, lane, wave, nw, ts, tiles, shared);
