@@ -137,6 +137,19 @@ def main():
                 traffic = json.load(open(tf)).get("fill_kernel_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        # supplementary: the bound that actually holds for this integer recurrence is instruction issue (DESIGN.md
+        # 4.1).  Instructions per pair come from the committed PMC run and are only valid for the default workload.
+        issue = None
+        try:
+            ipp = json.load(open(tf)).get("sweep_insts_per_pair_headline") if os.path.exists(tf) else None
+            if ipp and (m, args.ref_len) == (150, 2000) and args.mode in (None, 1) and fill_avg_s > 0:
+                insts = (ipp["valu"] + ipp["salu"]) * len(refs) * len(reads)
+                peak = 1024 * 2.4e9 / 4.45           # SIMDs x max clock / cycles per instruction of ONE wave per SIMD (tools/ubench.hip)
+                issue = {"insts_per_launch": insts, "achieved_ginst_s": round(insts / fill_avg_s / 1e9, 1),
+                         "peak_ginst_s_one_wave_per_simd": round(peak / 1e9, 1),
+                         "frac": round(insts / fill_avg_s / peak, 4)}
+        except Exception:
+            issue = None
         out = {
             "metric": "GCUPS", "value": round(gcups, 3), "unit": "GCUPS (1e9 DP cell updates/s, full path)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -157,6 +170,8 @@ def main():
                          "traceback_avg_ms": round(tb_ms / args.steps, 4), "d2h_avg_ms": round(d2h_ms / args.steps, 4)},
             "check": {"winner_ref": winner, "winner_total": batch.ref_total(winner)},
         }
+        if issue:
+            out["roofline"]["issue"] = issue
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(refs, reads)
         print(json.dumps(out))

@@ -757,7 +757,8 @@ __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDes
             uint32_t score = (uint32_t)po.score;
             uint32_t n_ops = 0;
             int begin = 0;
-            while ((int)score > 0) {
+            while ((int)score > 0 && i != 0u && j != 0u) {     // (a positive score at row/column 0 cannot happen with consistent
+                                                               //  data; the test keeps a corrupted workspace from walking off the matrix)
                 // ---- stage the window that holds the current cell's step ----
                 const uint32_t s = (i - 1u) / rps;
                 int rho = (int)((i - 1u) - s * rps);                               // row slot within the strip
