@@ -89,16 +89,49 @@ def main():
     gids = np.arange(id0, id0 + len(refs), dtype=np.int64)
 
     reducer = None
-    if world > 1 and not one_gpu:
-        reducer = swd.MaxReducer(dev)          # buffers allocated once; one RCCL all-gather per step
+    if world > 1:
+        reducer = swd.MaxReducer("cpu" if one_gpu else dev)    # buffers allocated once; one RCCL all-gather per step
+
+    # The path's one exchange step (max total + its references) runs on a helper thread, one step behind, the way a
+    # driver streaming shards would: batch.run() releases the GIL while it waits for the GPU, so the collective's
+    # host-side cost (~45 us of torch/RCCL calls) and its latency hide behind the next shard's kernels.  Every
+    # exchange of the timed steps has completed before the timed region ends (drain()).
+    import queue
+    import threading
+    work = queue.Queue()
+    results = []
+
+    def reduce_worker():
+        if dev.type == "cuda":
+            torch.cuda.set_device(dev)
+        while True:
+            item = work.get()
+            if item is None:
+                work.task_done()
+                return
+            try:
+                results.append(reducer(item, gids))
+            except BaseException as e:          # surfaced by drain()
+                results.append(e)
+            work.task_done()
+
+    worker = None
+    if reducer is not None:
+        worker = threading.Thread(target=reduce_worker, daemon=True)
+        worker.start()
 
     def step():
         batch.run(params)
-        if world > 1:      # the path's one exchange step: max total + its references
-            if reducer is not None:
-                return reducer(batch.ref_totals(), gids)
-            return swd.global_max_with_ties(batch.ref_totals(), gids, device=dev)
-        return None
+        if worker is not None:
+            work.put(batch.ref_totals().copy())
+
+    def drain():
+        if worker is not None:
+            work.join()
+            for r in results:
+                if isinstance(r, BaseException):
+                    raise r
+        return results[-1] if results else None
 
     def sync():
         if world > 1:
@@ -107,6 +140,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    drain()
     sync()
     fill_ms = tb_ms = d2h_ms = 0.0
     launches = 0
@@ -115,7 +149,11 @@ def main():
         step()
         t = batch.timing()
         fill_ms += t.fill_ms; tb_ms += t.traceback_ms; d2h_ms += t.d2h_ms; launches += t.fill_launches
+    last = drain()
     sync()
+    if worker is not None:
+        work.put(None)
+        worker.join()
     elapsed = time.perf_counter() - t0
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:

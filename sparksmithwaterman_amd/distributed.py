@@ -58,46 +58,75 @@ def global_max_with_ties(local_totals, global_ids, device=None, group=None, cap=
 
 class MaxReducer:
     """The same reduce as global_max_with_ties with every buffer allocated once: per call one pinned->device
-    copy, one all_gather_into_tensor (RCCL), one device->pinned copy, one stream sync.  For the per-step reduce of
-    bench.py, where the collective's latency is all there is to pay."""
+    copy, one all_gather_into_tensor (RCCL), one device->pinned copy, one event wait.  For the per-step reduce of
+    bench.py, where the collective's latency is all there is to pay.
 
-    def __init__(self, device, cap=64, group=None):
-        self.cap, self.group, self.device = cap, group, device
+    submit() only enqueues the exchange and returns a ticket; collect(ticket) waits for it and decodes.  A driver
+    that streams shards (bench.py) submits step k and collects step k-1, so the collective's latency hides behind
+    the next shard's kernels (the library runs on its own HIP stream).  `depth` exchanges may be in flight."""
+
+    def __init__(self, device, cap=64, group=None, depth=2, always_exchange=False):
+        self.cap, self.group, self.device, self.depth = cap, group, device, depth
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.exchange = self.world > 1 or (always_exchange and dist.is_initialized())   # (1-rank groups: rehearsal only)
         on_gpu = torch.device(device).type == "cuda"
-        self.h_pay = torch.empty(cap + 2, dtype=torch.int64, pin_memory=on_gpu)
-        self.d_pay = torch.empty(cap + 2, dtype=torch.int64, device=device)
-        self.d_all = torch.empty(self.world * (cap + 2), dtype=torch.int64, device=device)
-        self.h_all = torch.empty(self.world * (cap + 2), dtype=torch.int64, pin_memory=on_gpu)
+        self.on_gpu = on_gpu
         self.flat_gather = dist.is_initialized() and dist.get_backend(group) != "gloo"
-        self.pay_np = self.h_pay.numpy()
-        self.all_np = self.h_all.numpy().reshape(self.world, cap + 2)
+        self.slots = []
+        for _ in range(depth):
+            h_pay = torch.empty(cap + 2, dtype=torch.int64, pin_memory=on_gpu)
+            h_all = torch.empty(self.world * (cap + 2), dtype=torch.int64, pin_memory=on_gpu)
+            self.slots.append({
+                "h_pay": h_pay, "pay_np": h_pay.numpy(),
+                "d_pay": torch.empty(cap + 2, dtype=torch.int64, device=device),
+                "d_all": torch.empty(self.world * (cap + 2), dtype=torch.int64, device=device),
+                "h_all": h_all, "all_np": h_all.numpy().reshape(self.world, cap + 2),
+                "event": torch.cuda.Event() if on_gpu else None, "local": None,
+            })
+        self.n_submitted = 0
 
-    def __call__(self, local_totals, global_ids):
+    def submit(self, local_totals, global_ids):
         import numpy as np
         t = np.asarray(local_totals)
         local_best = max(int(t.max()), 0) if t.size else 0
         mine = np.asarray(global_ids)[t == local_best][:self.cap] if t.size else np.empty(0, dtype=np.int64)
-        if self.world == 1:
-            return local_best, sorted(int(x) for x in mine)
-        self.pay_np[0] = local_best
-        self.pay_np[1] = mine.size
-        self.pay_np[2:2 + mine.size] = mine
-        self.d_pay.copy_(self.h_pay, non_blocking=True)
+        ticket = self.n_submitted
+        self.n_submitted += 1
+        sl = self.slots[ticket % self.depth]
+        sl["local"] = (local_best, sorted(int(x) for x in mine))
+        if not self.exchange:
+            return ticket
+        sl["pay_np"][0] = local_best
+        sl["pay_np"][1] = mine.size
+        sl["pay_np"][2:2 + mine.size] = mine
+        sl["d_pay"].copy_(sl["h_pay"], non_blocking=True)
         if self.flat_gather:
-            dist.all_gather_into_tensor(self.d_all, self.d_pay, group=self.group)
+            dist.all_gather_into_tensor(sl["d_all"], sl["d_pay"], group=self.group)
         else:       # gloo (CPU tests) has no flat-tensor all-gather
-            dist.all_gather(list(self.d_all.view(self.world, self.cap + 2).unbind(0)), self.d_pay, group=self.group)
-        self.h_all.copy_(self.d_all, non_blocking=True)
-        if self.d_all.is_cuda:
-            torch.cuda.current_stream(self.d_all.device).synchronize()
-        g = self.all_np
+            dist.all_gather(list(sl["d_all"].view(self.world, self.cap + 2).unbind(0)), sl["d_pay"], group=self.group)
+        sl["h_all"].copy_(sl["d_all"], non_blocking=True)
+        if sl["event"] is not None:
+            sl["event"].record()
+        return ticket
+
+    def collect(self, ticket):
+        if ticket < self.n_submitted - self.depth or ticket >= self.n_submitted:
+            raise ValueError("ticket %d is not in flight" % ticket)
+        sl = self.slots[ticket % self.depth]
+        if not self.exchange:
+            return sl["local"]
+        if sl["event"] is not None:
+            sl["event"].synchronize()
+        g = sl["all_np"]
         gbest = int(g[:, 0].max())
         winners = []
         for row in g:
             if int(row[0]) == gbest:
                 winners.extend(int(x) for x in row[2:2 + int(row[1])])
         return gbest, sorted(winners)
+
+    def __call__(self, local_totals, global_ids):
+        return self.collect(self.submit(local_totals, global_ids))
 
 
 def global_top_k(local_totals, global_ids, k, device=None, group=None):

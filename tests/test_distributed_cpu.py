@@ -28,6 +28,16 @@ def _worker(rank, world, port, q):
     red = swd.MaxReducer("cpu")                                 # the preallocated-buffer form bench.py uses over RCCL
     assert red(totals_all[lo:hi], list(range(lo, hi))) == (best, winners)
     assert red([-3, -1], [lo, lo + 1]) == (0, [])
+    # pipelined form: two exchanges in flight, collected in order (what bench.py's step loop does)
+    t1 = red.submit(totals_all[lo:hi], list(range(lo, hi)))
+    t2 = red.submit([7, 7] if rank == 0 else [7, 3], [lo, lo + 1])
+    assert red.collect(t1) == (best, winners)
+    assert red.collect(t2) == (7, [0, 1, 4])
+    try:
+        red.collect(t1 - 5)
+        assert False, "a ticket that left the ring must be refused"
+    except ValueError:
+        pass
     q.put((rank, best, winners, topk, neg))
     dist.destroy_process_group()
 
