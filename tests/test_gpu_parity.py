@@ -217,3 +217,58 @@ def test_ncbi_shaped_batch_checksums(ctx):
     es, ea = orc.opt_alignments((refs[w], reads[0]))
     assert b.score(w) == es and b.alignments(w) == ea
     b.free()
+
+
+def _planted(rng, read, n, starts, alphabet="T"):
+    """A reference of `alphabet` filler with exact copies of `read` at the given 0-based starts (read has no filler base)."""
+    ref = [rng.choice(alphabet) for _ in range(n)]
+    for s in starts:
+        ref[s:s + len(read)] = list(read)
+    return "".join(ref)
+
+
+def test_tied_maxima_across_checkpoint_windows(ctx):
+    """Exact copies of the read planted in an all-T reference: every copy ends in a tied maximum cell, so the number of
+    alignments, the windows they end in and their distance from the reference's ends are under control.  Exercises the
+    mode-1 traceback's teams (1, 2, 3-4 and more than 4 alignments per pair), candidates at the very first / last columns,
+    copies that straddle 32-step checkpoint windows, several maxima inside one window, and both workgroup shapes
+    (8 waves per pair for batches of <= 512 pairs, 4 otherwise)."""
+    rng = random.Random(20261004)
+    read100 = "".join(rng.choice("ACG") for _ in range(100))
+    read10 = "".join(rng.choice("ACG") for _ in range(10))
+    read200 = "".join(rng.choice("ACG") for _ in range(200))       # R = 4 rows per lane
+    cases = [
+        (read100, 700, [0]),                          # the alignment starts in column 1
+        (read100, 700, [600]),                        # ... and ends in the last column
+        (read100, 700, [13, 300]),                    # two candidates
+        (read100, 700, [5, 210, 420]),                # three: one walker each, no helpers in a 4-wave workgroup
+        (read100, 900, [0, 130, 260, 390, 520, 650, 780]),   # more alignments than walkers
+        (read100, 333, [27, 156]),                    # ends at steps 126/255: last column of a window
+        (read10, 300, [3, 14, 25, 36, 200]),          # several maxima inside one window (more cells than candidates)
+        (read10, 40, [0, 30]),                        # reference shorter than two windows
+        (read200, 1000, [100, 500, 777]),
+        (read200, 260, [60]),
+    ]
+    refs, reads_for = [], []
+    for read, n, starts in cases:
+        refs.append(_planted(rng, read, n, starts))
+        reads_for.append(read)
+    # one batch per read (a batch is refs x reads); small batches run 8 waves per pair
+    for read in (read100, read10, read200):
+        rs = [r for r, q in zip(refs, reads_for) if q is read]
+        for tie in (0, 1):
+            check_batch(ctx, rs, [read], tie=tie)
+    # the same references repeated past 512 pairs: 4 waves per pair
+    rs = [r for r, q in zip(refs, reads_for) if q is read100]
+    many = (rs * 110)[:560]
+    b = ctx.upload(many, [read100]).run(sw.make_params())
+    try:
+        want = {}
+        for k, ref in enumerate(many):
+            if ref not in want:
+                want[ref] = orc.opt_alignments((ref, read100), (5, -3, -4), b"aid-", 0, with_cells=True)
+            es, ea = want[ref]
+            assert b.score(k) == es
+            assert b.alignments(k, with_cell=True) == ea, k
+    finally:
+        b.free()
