@@ -417,7 +417,17 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
         dir_words += w.dir_words;
         seam_words += w.seam_words;
         pd[k] = d;
-        max_path = std::max(max_path, b->ref_desc[d.ref_id].len + b->read_desc[d.read_id].len);
+        {
+            // longest possible traceback: A + I <= m rows, A + D <= n columns, and -- with match > 0 > gap -- the score
+            // match*A + gap*(I + D) must stay positive (`while (score > 0)`), which caps the gap moves
+            const uint64_t n_ = b->ref_desc[d.ref_id].len, m_ = b->read_desc[d.read_id].len;
+            uint64_t path = n_ + m_;
+            if (b->params.match > 0 && b->params.gap < 0 && b->params.mismatch <= b->params.match) {
+                const uint64_t g = (uint64_t)(-(int64_t)b->params.gap), mt = (uint64_t)b->params.match;
+                path = std::min(path, std::min(m_ + std::min(n_, mt * m_ / g), n_ + std::min(m_, mt * n_ / g)));
+            }
+            max_path = std::max<uint32_t>(max_path, (uint32_t)path);
+        }
         max_read = std::max(max_read, b->read_desc[d.read_id].len);
     }
     if ((rc = b->d_pairs.reserve(np * sizeof(PairDesc)))) return rc;
@@ -455,8 +465,18 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
 
     const uint32_t lds_words = (max_path + 3) / 4 + 1;        // one staged op per byte
     const uint32_t lds_read_words = (max_read + 3) / 4 + 1;
-    if ((lds_words + lds_read_words) * 4ull > 128 * 1024)
-        return fail(SWMI_ERR_UNSUPPORTED, "a pair of %u bases in total does not fit the traceback's LDS staging", max_path);
+    {
+        // the traceback stages one alignment's ops and the read per walker (4 per workgroup) next to its direction tiles:
+        // 160 KB of LDS per workgroup bound the longest pair (m + n of about 16 k bases in mode 0, 24 k in modes 1/2)
+        // (swmi_kernels.hip: SWMI_TB_BLOCKS = 16 blocks per mode-0 tile, SWMI_TB_WAVES = 8, SWMI_TB_REFWIN_WORDS = 96)
+        const uint64_t win = (uint64_t)SWMI_RMAX * 64;
+        const uint64_t tile_words = b->eff_mode == 0 ? 4ull * 16 * win
+                                  : (b->eff_mode == 1 ? 32 + 8ull * SWMI_CK_BLOCKS * win : 4ull * SWMI_CK_BLOCKS * win);
+        const uint64_t need = 4ull * (tile_words + 4ull * ((uint64_t)lds_words + lds_read_words + 96));
+        if (need > 160ull * 1024)
+            return fail(SWMI_ERR_UNSUPPORTED, "a pair of %u bases in total needs %llu bytes of LDS for the traceback (limit 163840)",
+                        max_path, (unsigned long long)need);
+    }
 
     const auto c0 = std::chrono::steady_clock::now();
     uint64_t arena_cap = std::max<uint64_t>(np * ctx->arena_words_per_pair, 1024);

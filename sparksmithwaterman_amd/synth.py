@@ -28,8 +28,15 @@ class SplitMix64:
             z = (z ^ (z >> np.uint64(27))) * _M2
             return z ^ (z >> np.uint64(31))
 
-    def bases(self, n):
-        return _ACGT[(self.next(n) >> np.uint64(62)).astype(np.int64)].tobytes()
+    def bases(self, n, chunk=1 << 24):
+        """n bases; drawn in chunks (same stream, same result) so that 10^9 bases do not need 10^10 bytes of temporaries"""
+        if n <= chunk:
+            return _ACGT[(self.next(n) >> np.uint64(62)).astype(np.int64)].tobytes()
+        out = np.empty(n, dtype=np.uint8)
+        for lo in range(0, n, chunk):
+            k = min(chunk, n - lo)
+            out[lo:lo + k] = _ACGT[(self.next(k) >> np.uint64(62)).astype(np.int64)]
+        return out.tobytes()
 
     def uniform(self, n=1):
         return (self.next(n) >> np.uint64(11)).astype(np.float64) * (1.0 / (1 << 53))
