@@ -426,6 +426,13 @@ __device__ __forceinline__ void fill_pair(const FillArgs &A, const PairDesc pd, 
         const uint32_t nblk = (T + 15u) / 16u;
         const uint4 *__restrict__ refq = reinterpret_cast<const uint4 *>(refw);   // images are 16-byte aligned
         uint4 wnext = refq[0];
+        // seam_in[16tb + 1 + lane] for lanes 0..15: N of lane 0 for the 16 steps of block tb -- loaded one block ahead,
+        // like the base codes, so that the sweep never waits for it
+        auto load_seam = [&](uint32_t tb) -> int {
+            const uint32_t col = 16u * tb + 1u + (lane & 15u);
+            return col <= n ? __hip_atomic_load(seam_in + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        };
+        int seam_next = reads_seam ? load_seam(0u) : 0;
         for (uint32_t tb = 0; tb < nblk; ++tb) {
             const uint4 w = wnext;                       // base codes of columns 16tb+1 .. 16tb+16
             wnext = refq[tb + 1];                        // prefetch (images are padded)
@@ -439,12 +446,8 @@ __device__ __forceinline__ void fill_pair(const FillArgs &A, const PairDesc pd, 
                 ck[R * WAVE] = (uint32_t)S.nprev;
                 ck[(R + 1) * WAVE] = (uint32_t)S.rb;
             }
-            int seamv = 0;
-            if (reads_seam) {
-                // seam_in[16tb + 1 + lane] for lanes 0..15: N of lane 0 for the 16 steps of this block
-                const uint32_t col = t0 + 1u + (lane & 15u);
-                seamv = col <= n ? __hip_atomic_load(seam_in + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-            }
+            const int seamv = seam_next;
+            if (reads_seam) seam_next = load_seam(tb + 1u);
             const bool steady = (t0 + 1u >= lact) && (t0 + 15u < n);
             if (steady)
                 fill_block16<R, ACGT, STRICT, MULTI, false, MODE>(S, w, t0, lane, lane_eff, n, m, row0, gap, match, mismatch,
