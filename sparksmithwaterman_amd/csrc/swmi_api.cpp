@@ -138,6 +138,7 @@ struct swmi_batch {
     std::vector<SeqDesc> ref_desc, read_desc;
     // device
     DevBuf d_seqw, d_refs, d_reads, d_pairs, d_dir, d_seam, d_result, d_cells, d_cells_off, d_cells_cap, d_dbg, d_dbg2;
+    DevBuf d_strip_items, d_progress;       // mode 1: strip-per-wavefront sweep of long reads
     PinnedBuf h_result;
     // per run
     swmi_params params{};
@@ -321,6 +322,7 @@ extern "C" void swmi_batch_free(swmi_ctx *ctx, swmi_batch *b) {
     b->d_seqw.release(); b->d_refs.release(); b->d_reads.release(); b->d_pairs.release();
     b->d_dir.release(); b->d_seam.release(); b->d_result.release(); b->d_cells.release();
     b->d_cells_off.release(); b->d_cells_cap.release(); b->d_dbg.release(); b->d_dbg2.release();
+    b->d_strip_items.release(); b->d_progress.release();
     b->h_result.release();
     delete b;
 }
@@ -404,6 +406,7 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
 
     // pair descriptors, direction-field and seam offsets
     std::vector<PairDesc> pd(np);
+    std::vector<uint2> strip_items;          // mode 1: (pair, strip) of every read longer than one strip, one wavefront each
     uint64_t dir_words = 0, seam_words = 0;
     uint32_t max_path = 0, max_read = 0;
     for (size_t k = 0; k < np; k++) {
@@ -416,6 +419,11 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
         d.seam_off = seam_words;
         dir_words += w.dir_words;
         seam_words += w.seam_words;
+        if (b->eff_mode == 1 && b->read_desc[d.read_id].len > 64u * SWMI_RMAX && strip_items.size() < (1u << 30)) {
+            const uint32_t strips = (b->read_desc[d.read_id].len + 64u * SWMI_RMAX - 1u) / (64u * SWMI_RMAX);
+            d.pad = (uint32_t)strip_items.size();
+            for (uint32_t st = 0; st < strips; st++) strip_items.push_back(make_uint2((uint32_t)k, st));
+        }
         pd[k] = d;
         {
             // longest possible traceback: A + I <= m rows, A + D <= n columns, and -- with match > 0 > gap -- the score
@@ -431,6 +439,12 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
         max_read = std::max(max_read, b->read_desc[d.read_id].len);
     }
     if ((rc = b->d_pairs.reserve(np * sizeof(PairDesc)))) return rc;
+    if (!strip_items.empty()) {
+        if ((rc = b->d_strip_items.reserve(strip_items.size() * sizeof(uint2)))) return rc;
+        if ((rc = b->d_progress.reserve(strip_items.size() * sizeof(uint32_t)))) return rc;
+        HIP_TRY(hipMemcpyAsync(b->d_strip_items.p, strip_items.data(), strip_items.size() * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));      // strip_items is a local
+    }
     if ((rc = b->d_dir.reserve(std::max<uint64_t>(dir_words, 1) * 4))) return rc;
     if ((rc = b->d_seam.reserve(std::max<uint64_t>(seam_words, 1) * 4))) return rc;
     // repeated runs of one batch schedule the same pairs: skip the H2D copy when nothing changed
@@ -516,7 +530,11 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
         fa.match = b->params.match; fa.mismatch = b->params.mismatch; fa.gap = b->params.gap;
         fa.strict = b->params.tie_mode == SWMI_TIE_STRICT;
         fa.mode = b->eff_mode;
-        fa.pad2 = 0;
+        fa.skip_multi = strip_items.empty() ? 0u : 1u;
+        fa.strip_items = strip_items.empty() ? nullptr : b->d_strip_items.as<uint2>();
+        fa.progress = strip_items.empty() ? nullptr : b->d_progress.as<uint32_t>();
+        fa.n_strip_items = (uint32_t)strip_items.size();
+        fa.pad3 = 0;
 
         TraceArgs &ta = rs.ta;
         ta.seqw = fa.seqw; ta.refs = fa.refs; ta.reads = fa.reads; ta.pairs = fa.pairs;
@@ -552,6 +570,7 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
         }
 
         if (attempt == 0) {       // the workspace survives an arena-overflow retry
+            if (fa.n_strip_items) HIP_TRY(hipMemsetAsync(fa.progress, 0, (size_t)fa.n_strip_items * sizeof(uint32_t), ctx->stream));
             if (ctx->profiling) HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
             HIP_TRY(swmi_launch_fill(&fa, ctx->stream));
             rs.launches++;

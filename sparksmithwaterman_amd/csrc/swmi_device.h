@@ -53,7 +53,7 @@ struct PairDesc {
     uint32_t ref_id;
     uint32_t read_id;
     uint32_t out_id;      // index into out[] / cells[] (the pair's position in the batch)
-    uint32_t pad;
+    uint32_t pad;         // mode 1, pairs of several strips: index of the pair's first entry in FillArgs.progress
     uint64_t dir_off;     // dword offset of this pair's direction field in dir[]
     uint64_t seam_off;    // dword offset of the strip-seam rows, n+1 int32 per strip (multi-strip pairs only)
 };
@@ -100,7 +100,12 @@ struct FillArgs {
     int32_t         match, mismatch, gap;
     uint32_t        strict;      // tie mode
     uint32_t        mode;        // 0 = direction field in HBM, 1 = checkpoints + window maxima, 2 = checkpoints + event-tracked maxima
-    uint32_t        pad2;
+    uint32_t        skip_multi;  // mode 1: the pairs of several strips are left to sw_sweep_winmax_strips_kernel
+    // mode 1, reads longer than one strip: one wavefront per STRIP, pipelined through the seam rows
+    const uint2    *strip_items; // {pair index of this launch, strip}, the strips of a pair consecutive and ascending
+    uint32_t       *progress;    // per strip item: 16-step blocks finished (the item's index is PairDesc.pad + strip)
+    uint32_t        n_strip_items;
+    uint32_t        pad3;
 };
 
 struct TraceArgs {

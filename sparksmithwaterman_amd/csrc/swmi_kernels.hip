@@ -232,7 +232,7 @@ __device__ __forceinline__ void handle_pending(FillState<R> &S, const int (&hv)[
 // the values of step t-1 are still there.  That lets the tied-maximum test of step t-1 -- a compare into
 // an SGPR pair -- be branched on one step later, when its result has long arrived, instead of stalling the
 // wave on a VALU->scalar-branch dependency every step (measured: 57 of 197 cycles per step).
-template <int R, bool ACGT, bool STRICT, bool MULTI, bool PRED, int MODE>
+template <int R, bool ACGT, bool STRICT, bool MULTI, bool PRED, int MODE, bool PIPE = false>
 __device__ __forceinline__ void fill_block16(FillState<R> &S, const uint4 w, const uint32_t t0,
                                              const uint32_t lane, const uint32_t lane_eff,
                                              const uint32_t n, const uint32_t m, const uint32_t row0,
@@ -288,7 +288,10 @@ __device__ __forceinline__ void fill_block16(FillState<R> &S, const uint4 w, con
 #pragma unroll
                     for (int k = 0; k < R; ++k) S.lmax = S.lmax > hout[k] ? S.lmax : hout[k];
                 }
-                if (MULTI && FEEDS && feeds_seam && lane == WAVE - 1) seam_out[c0 + 1] = hout[R - 1];
+                if (MULTI && FEEDS && feeds_seam && lane == WAVE - 1) {
+                    if (PIPE) __hip_atomic_store(seam_out + c0 + 1, hout[R - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else      seam_out[c0 + 1] = hout[R - 1];
+                }
             } else {
 #pragma unroll
                 for (int k = 0; k < R; ++k) hout[k] = hin[k];             // a lane off its range keeps its state
@@ -316,7 +319,11 @@ __device__ __forceinline__ void fill_block16(FillState<R> &S, const uint4 w, con
                     for (int k = 0; k < R; ++k) S.lmax = S.lmax > hout[k] ? S.lmax : hout[k];
                 }
             }
-            if (MULTI && FEEDS && feeds_seam && lane == WAVE - 1) seam_out[t0 + s - lane + 1] = hout[R - 1];
+            if (MULTI && FEEDS && feeds_seam && lane == WAVE - 1) {
+                // PIPE: another wavefront (possibly on another XCD) is already reading this row: device-coherent store
+                if (PIPE) __hip_atomic_store(seam_out + (t0 + s - lane + 1), hout[R - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else      seam_out[t0 + s - lane + 1] = hout[R - 1];
+            }
         }
         S.nprev = nin;
         if (DETECT) {
@@ -370,8 +377,11 @@ __device__ __forceinline__ StripGeom strip_geom(uint32_t m, uint32_t n, uint32_t
 // signed byte (profile lookup by v_bfe_i32 instead of compare+select); STRICT = DistributedSW tie order;
 // MULTI = more than one strip of 64*R rows (seam rows through memory); MODE = FIELD or SCORE.
 // ------------------------------------------------------------------------------------------------
-template <int R, bool ACGT, bool STRICT, bool MULTI, int MODE>
-__device__ __forceinline__ void fill_pair(const FillArgs &A, const PairDesc pd, const uint32_t lane) {
+// PIPE (mode 1, MULTI): this wavefront sweeps only strip `my_strip`; the wavefront of strip s-1 runs a few blocks ahead
+// and publishes its progress, the one of strip s+1 follows -- a systolic pipeline of strips over wavefronts, so a
+// 10 kbp read is swept in about the time of ONE strip instead of 40.
+template <int R, bool ACGT, bool STRICT, bool MULTI, int MODE, bool PIPE = false>
+__device__ __forceinline__ void fill_pair(const FillArgs &A, const PairDesc pd, const uint32_t lane, const uint32_t my_strip = 0u) {
     const SeqDesc rd = A.refs[pd.ref_id];
     const SeqDesc qd = A.reads[pd.read_id];
     const uint32_t n = rd.len, m = qd.len;
@@ -394,7 +404,15 @@ __device__ __forceinline__ void fill_pair(const FillArgs &A, const PairDesc pd, 
     S.dbg_skip = A.dbg && (A.dbg_pad != 0);
     const unsigned long long t_start = A.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
 
-    for (uint32_t s = 0; s < G.n_strips; ++s) {
+    const uint32_t s_begin = PIPE ? my_strip : 0u, s_end = PIPE ? my_strip + 1u : G.n_strips;
+    uint32_t *__restrict__ progress = PIPE ? A.progress + pd.pad : nullptr;
+    if (PIPE && my_strip == 0u && lane == 0) {
+        // the pair's result is assembled by atomics from all its strips: start from zero (every other strip touches it
+        // only after it has seen progress of this one)
+        __hip_atomic_store(&A.out[pd.out_id].score, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store((unsigned long long *)&A.out[pd.out_id].n_cells, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    for (uint32_t s = s_begin; s < s_end; ++s) {
         const uint32_t row0 = s * G.rps + lane * R;        // 0-based first row of this lane
         const uint32_t rows_left = m - s * G.rps;
         const uint32_t lact = rows_left >= G.rps ? WAVE : (rows_left + R - 1) / R;   // lanes holding rows
@@ -428,7 +446,19 @@ __device__ __forceinline__ void fill_pair(const FillArgs &A, const PairDesc pd, 
         uint4 wnext = refq[0];
         // seam_in[16tb + 1 + lane] for lanes 0..15: N of lane 0 for the 16 steps of block tb -- loaded one block ahead,
         // like the base codes, so that the sweep never waits for it
+        // PIPE: column c of the seam row is stored by the producer's lane 63 at step c + 62; the columns of block x are
+        // complete when the producer has finished block x + 4
+        const uint32_t nblk_prod = (n + WAVE - 1u + 15u) / 16u;
+        bool gave_up = false;
         auto load_seam = [&](uint32_t tb) -> int {
+            if (PIPE) {
+                const uint32_t need = tb + 5u < nblk_prod ? tb + 5u : nblk_prod;
+                uint32_t spins = 0;
+                while (!gave_up && __hip_atomic_load(progress + (s - 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+                    __builtin_amdgcn_s_sleep(8);
+                    if (++spins > (1u << 18)) gave_up = true;   // a producer that never comes (~60 ms): wrong results beat a hung GPU
+                }
+            }
             const uint32_t col = 16u * tb + 1u + (lane & 15u);
             return col <= n ? __hip_atomic_load(seam_in + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
         };
@@ -450,11 +480,16 @@ __device__ __forceinline__ void fill_pair(const FillArgs &A, const PairDesc pd, 
             if (reads_seam) seam_next = load_seam(tb + 1u);
             const bool steady = (t0 + 1u >= lact) && (t0 + 15u < n);
             if (steady)
-                fill_block16<R, ACGT, STRICT, MULTI, false, MODE>(S, w, t0, lane, lane_eff, n, m, row0, gap, match, mismatch,
-                                                                  seamv, reads_seam, feeds_seam, seam_out, cells, ccap);
+                fill_block16<R, ACGT, STRICT, MULTI, false, MODE, PIPE>(S, w, t0, lane, lane_eff, n, m, row0, gap, match, mismatch,
+                                                                        seamv, reads_seam, feeds_seam, seam_out, cells, ccap);
             else
-                fill_block16<R, ACGT, STRICT, MULTI, true, MODE>(S, w, t0, lane, lane_eff, n, m, row0, gap, match, mismatch,
-                                                                 seamv, reads_seam, feeds_seam, seam_out, cells, ccap);
+                fill_block16<R, ACGT, STRICT, MULTI, true, MODE, PIPE>(S, w, t0, lane, lane_eff, n, m, row0, gap, match, mismatch,
+                                                                       seamv, reads_seam, feeds_seam, seam_out, cells, ccap);
+            if (PIPE && feeds_seam) {
+                // this block's seam stores have left the CU (they are device-coherent stores): publish the progress
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_store(progress + s, tb + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
 
             if (MODE == SWMI_MODE_FIELD) {
                 // ---- end of a 16-step block: one coalesced 256 B store per row slot -------------------
@@ -477,6 +512,22 @@ __device__ __forceinline__ void fill_pair(const FillArgs &A, const PairDesc pd, 
         if (MULTI) __threadfence();    // seam row of this strip visible before the next strip reads it
     }
 
+    if (PIPE) {
+        // combine the strips: maximum by atomicMax, the last strip to finish completes the record
+        if (lane == 0) {
+            PairOut *o = &A.out[pd.out_id];
+            if (pair_max > 0) atomicMax(&o->score, pair_max);
+            __threadfence();
+            const unsigned long long done = atomicAdd((unsigned long long *)&o->n_cells, 1ull);
+            if (done + 1ull == (unsigned long long)G.n_strips) {
+                __threadfence();
+                const int best = __hip_atomic_load(&o->score, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (best <= 0) { o->flags = SWMI_F_DEGENERATE; o->n_cells = (uint64_t)m * n; }
+                else           { o->flags = 0u; o->n_cells = 0; }
+            }
+        }
+        return;
+    }
     if (lane == 0) {
         PairOut o;
         if (MODE == SWMI_MODE_WINMAX) {
@@ -515,6 +566,7 @@ __device__ __forceinline__ void fill_entry(const FillArgs &A) {
     const PairDesc pd = A.pairs[pair];
     const SeqDesc rd = A.refs[pd.ref_id];
     const SeqDesc qd = A.reads[pd.read_id];
+    if (MODE == SWMI_MODE_WINMAX && A.skip_multi && qd.len > WAVE * SWMI_RMAX) return;   // swept strip by strip, see below
     // profile lookup needs both sequences pure ACGT and scores that fit a signed byte
     const bool acgt = rd.acgt && qd.acgt &&
                       A.match >= -128 && A.match <= 127 && A.mismatch >= -128 && A.mismatch <= 127;
@@ -538,6 +590,23 @@ sw_fill_score_kernel(const FillArgs A) { fill_entry<SWMI_MODE_SCORE>(A); }
 
 extern "C" __global__ void __launch_bounds__(WAVE * FILL_WAVES)
 sw_sweep_winmax_kernel(const FillArgs A) { fill_entry<SWMI_MODE_WINMAX>(A); }
+
+// mode 1, reads of several strips: one wavefront per (pair, strip).  The items are ordered so that a strip's producer
+// (the strip above it) sits in the same or an earlier workgroup, i.e. is never dispatched later than its consumer.
+extern "C" __global__ void __launch_bounds__(WAVE * FILL_WAVES)
+sw_sweep_winmax_strips_kernel(const FillArgs A) {
+    const uint32_t item = blockIdx.x * FILL_WAVES + (threadIdx.x >> 6);
+    if (item >= A.n_strip_items) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint2 it = A.strip_items[item];
+    const PairDesc pd = A.pairs[it.x];
+    const SeqDesc rd = A.refs[pd.ref_id];
+    const SeqDesc qd = A.reads[pd.read_id];
+    const bool acgt = rd.acgt && qd.acgt &&
+                      A.match >= -128 && A.match <= 127 && A.mismatch >= -128 && A.mismatch <= 127;
+    if (acgt) fill_pair<SWMI_RMAX, true, false, true, SWMI_MODE_WINMAX, true>(A, pd, lane, it.y);
+    else      fill_pair<SWMI_RMAX, false, false, true, SWMI_MODE_WINMAX, true>(A, pd, lane, it.y);
+}
 
 // ------------------------------------------------------------------------------------------------
 // traceback: SWMI_TB_SLOTS wavefronts per pair (slot x walks the tied cells x, x+SLOTS, ...).
@@ -1257,7 +1326,11 @@ extern "C" hipError_t swmi_launch_fill(const FillArgs *a, hipStream_t st) {
     if (a->n_pairs == 0) return hipSuccess;
     const dim3 grid((a->n_pairs + FILL_WAVES - 1) / FILL_WAVES), block(WAVE * FILL_WAVES);
     if (a->mode == 0)      hipLaunchKernelGGL(sw_fill_kernel, grid, block, 0, st, *a);
-    else if (a->mode == 1) hipLaunchKernelGGL(sw_sweep_winmax_kernel, grid, block, 0, st, *a);
+    else if (a->mode == 1) {
+        hipLaunchKernelGGL(sw_sweep_winmax_kernel, grid, block, 0, st, *a);
+        if (a->skip_multi && a->n_strip_items)
+            hipLaunchKernelGGL(sw_sweep_winmax_strips_kernel, dim3((a->n_strip_items + FILL_WAVES - 1) / FILL_WAVES), block, 0, st, *a);
+    }
     else                   hipLaunchKernelGGL(sw_fill_score_kernel, grid, block, 0, st, *a);
     return hipGetLastError();
 }
