@@ -703,10 +703,9 @@ __device__ __forceinline__ uint32_t replay_dispatch(const TraceArgs &A, const Pa
     }
 }
 
-// true for the pairs the full-featured mode-1 traceback handles: pure ACGT with int8 scores, the serial tie order, one strip
+// true for the pairs the full-featured mode-1 traceback handles: pure ACGT with int8 scores, the serial tie order
 __device__ __forceinline__ bool swmi_common_pair(const TraceArgs &A, const SeqDesc rd, const SeqDesc qd) {
-    return rd.acgt && qd.acgt && A.match >= -128 && A.match <= 127 && A.mismatch >= -128 && A.mismatch <= 127 &&
-           !A.strict && qd.len <= WAVE * SWMI_RMAX;
+    return rd.acgt && qd.acgt && A.match >= -128 && A.match <= 127 && A.mismatch >= -128 && A.mismatch <= 127 && !A.strict;
 }
 
 // re-sweeps one window.  FULL: any variant (byte alphabet, DistributedSW tie order, several strips); otherwise only the
@@ -717,8 +716,13 @@ __device__ __forceinline__ uint32_t replay_any(const TraceArgs &A, const PairDes
                                                const uint32_t *__restrict__ refw, const uint32_t *__restrict__ readw,
                                                const StripGeom G, uint32_t s, uint32_t wlo, uint32_t lane, uint32_t *lds_tile,
                                                int maxv, uint32_t cnt_in, uint2 *__restrict__ cells, uint32_t ccap) {
-    if constexpr (!FULL)
+    if constexpr (!FULL) {
+        if constexpr (R == SWMI_RMAX) {
+            if (m > WAVE * SWMI_RMAX)          // a read of several strips
+                return replay_window<R, true, false, true, DETECT>(A, pd, n, m, refw, readw, G, s, wlo, lane, lds_tile, maxv, cnt_in, cells, ccap);
+        }
         return replay_window<R, true, false, false, DETECT>(A, pd, n, m, refw, readw, G, s, wlo, lane, lds_tile, maxv, cnt_in, cells, ccap);
+    }
     if constexpr (R == SWMI_RMAX) {
         if (m > WAVE * SWMI_RMAX)
             return replay_dispatch<R, true, DETECT>(A, pd, n, m, acgt, refw, readw, G, s, wlo, lane, lds_tile, maxv, cnt_in, cells, ccap);
