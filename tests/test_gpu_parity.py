@@ -272,3 +272,20 @@ def test_tied_maxima_across_checkpoint_windows(ctx):
             assert b.alignments(k, with_cell=True) == ea, k
     finally:
         b.free()
+
+
+def test_long_reads_mixed_with_short_ones(ctx):
+    """Reads of one, two and three strips (256 rows each) in ONE batch, one of them outside ACGT: in mode 1 the long
+    ones are swept one wavefront per strip (pipelined through the seam rows) next to the ordinary one-wave pairs."""
+    rng = random.Random(77)
+    refs = ["".join(rng.choice("ACGT") for _ in range(n)) for n in (1500, 900, 1201)]
+
+    def cut(ref, m, alphabet="ACGT", every=11):
+        s = list(ref[100:100 + m])
+        for k in range(0, m, every):
+            s[k] = rng.choice(alphabet)
+        return "".join(s)
+
+    reads = [cut(refs[0], 700), cut(refs[1], 150), cut(refs[2], 300, "ACGTN", 7), cut(refs[0], 257, every=5)]
+    for tie in (0, 1):
+        check_batch(ctx, refs, reads, tie=tie)
