@@ -15,6 +15,7 @@ template <int V>
 __global__ void __launch_bounds__(256) k(int *out, int iters, long long *cyc) {
     int a = threadIdx.x, b = a * 3 + 1, c = a ^ 5, d = a + 7, e = 1, f = 2, g = 3, h = 4;
     unsigned acc = 0;
+    int lm = 0, rb = a & 0x01010101, dg = 1, gp = -4, l0 = 0, l1 = 0, l2 = 0;
     long long t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < iters; ++it) {
         if (V == 0) { asm volatile(REP64("v_add_u32 %0, %0, %1\n") : "+v"(a) : "v"(b)); }
@@ -61,12 +62,66 @@ __global__ void __launch_bounds__(256) k(int *out, int iters, long long *cyc) {
                 "v_max3_i32 %2, %0, %3, 0\n")
                 : "+v"(a), "+v"(c), "+v"(d), "+v"(e) : "v"(b), "v"(f), "v"(g));
         }
+        if (V == 14) {     // one R=3 step of the mode-1 sweep as generated: chain dpp -> 3 x (max, add, max3)
+            asm volatile(REP16(
+                "v_mov_b32_dpp %[n], %[h2] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+                "v_dot4_i32_i8 %[a0], %[q], %[rb], %[d]\n"
+                "v_max_i32 %[t], %[n], %[h0]\n"
+                "v_dot4_i32_i8 %[a1], %[q], %[rb], %[h0]\n"
+                "v_add_u32 %[t], %[gap], %[t]\n"
+                "v_dot4_i32_i8 %[a2], %[q], %[rb], %[h1]\n"
+                "v_max3_i32 %[h0], %[a0], %[t], 0\n"
+                "v_max_i32 %[t], %[h0], %[h1]\n"
+                "v_add_u32 %[t], %[gap], %[t]\n"
+                "v_max3_i32 %[h1], %[a1], %[t], 0\n"
+                "v_max_i32 %[t], %[h1], %[h2]\n"
+                "v_add_u32 %[t], %[gap], %[t]\n"
+                "v_max3_i32 %[h2], %[a2], %[t], 0\n"
+                "v_max3_i32 %[lm], %[lm], %[h0], %[h1]\n"
+                "v_mov_b32_dpp %[rb], %[rb] wave_shr:1 row_mask:0xf bank_mask:0xf\n"
+                "v_mov_b32 %[d], %[n]\n")
+                : [h0] "+v"(a), [h1] "+v"(c), [h2] "+v"(d), [n] "+v"(e), [t] "+v"(f), [a0] "+v"(g), [a1] "+v"(h), [a2] "+v"(acc), [lm] "+v"(lm), [rb] "+v"(rb), [d] "+v"(dg)
+                : [q] "v"(b), [gap] "v"(gp));
+        }
+        if (V == 15) {     // same step, row chain shortened to (add, max) per row: a'' = max3(a, left + gap, 0) is off the chain
+            asm volatile(REP16(
+                "v_mov_b32_dpp %[n], %[h2] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+                "v_dot4_i32_i8 %[a0], %[q], %[rb], %[d]\n"
+                "v_add_u32 %[l0], %[gap], %[h0]\n"
+                "v_dot4_i32_i8 %[a1], %[q], %[rb], %[h0]\n"
+                "v_add_u32 %[l1], %[gap], %[h1]\n"
+                "v_dot4_i32_i8 %[a2], %[q], %[rb], %[h1]\n"
+                "v_add_u32 %[l2], %[gap], %[h2]\n"
+                "v_max3_i32 %[a0], %[a0], %[l0], 0\n"
+                "v_add_u32 %[t], %[gap], %[n]\n"
+                "v_max3_i32 %[a1], %[a1], %[l1], 0\n"
+                "v_max_i32 %[h0], %[a0], %[t]\n"
+                "v_max3_i32 %[a2], %[a2], %[l2], 0\n"
+                "v_add_u32 %[t], %[gap], %[h0]\n"
+                "v_max_i32 %[h1], %[a1], %[t]\n"
+                "v_add_u32 %[t], %[gap], %[h1]\n"
+                "v_max_i32 %[h2], %[a2], %[t]\n"
+                "v_max3_i32 %[lm], %[lm], %[h0], %[h1]\n"
+                "v_mov_b32_dpp %[rb], %[rb] wave_shr:1 row_mask:0xf bank_mask:0xf\n"
+                "v_mov_b32 %[d], %[n]\n")
+                : [h0] "+v"(a), [h1] "+v"(c), [h2] "+v"(d), [n] "+v"(e), [t] "+v"(f), [a0] "+v"(g), [a1] "+v"(h), [a2] "+v"(acc), [lm] "+v"(lm), [rb] "+v"(rb), [d] "+v"(dg),
+                  [l0] "+v"(l0), [l1] "+v"(l1), [l2] "+v"(l2)
+                : [q] "v"(b), [gap] "v"(gp));
+        }
+        if (V == 16) {     // VOP3 sources all in ONE VGPR bank (index % 4 equal)
+            asm volatile(REP16("v_max3_i32 v40, v44, v48, v52\n v_max3_i32 v41, v45, v49, v53\n v_dot4_i32_i8 v42, v46, v50, v54\n v_max3_i32 v43, v47, v51, v55\n")
+                         ::: "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55");
+        }
+        if (V == 17) {     // ... in three different banks
+            asm volatile(REP16("v_max3_i32 v40, v44, v49, v54\n v_max3_i32 v41, v45, v50, v55\n v_dot4_i32_i8 v42, v46, v51, v52\n v_max3_i32 v43, v47, v48, v53\n")
+                         ::: "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55");
+        }
         if (V == 11) { int sa = it; asm volatile(REP64("s_add_u32 %0, %0, 3\n") : "+s"(sa)); a += sa; }
         if (V == 12) { int sa = it; asm volatile(REP16("s_add_u32 %0, %0, 3\n v_add_u32 %1, %1, %2\n s_add_u32 %0, %0, 5\n v_add_u32 %1, %1, %2\n") : "+s"(sa), "+v"(a) : "v"(b)); a += sa; }
         if (V == 13) { int sa = it; asm volatile(REP16("s_cmp_lg_u32 %0, 77\n s_cbranch_scc0 1f\n1:\n v_add_u32 %1, %1, %2\n s_add_u32 %0, %0, 5\n") : "+s"(sa), "+v"(a) : "v"(b) : "scc"); a += sa; }
     }
     long long t1 = __builtin_amdgcn_s_memtime();
-    out[blockIdx.x * blockDim.x + threadIdx.x] = a + c + d + e + (int)acc + f + g + h;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a + c + d + e + (int)acc + f + g + h + lm + rb + dg + l0 + l1 + l2;
     if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
@@ -120,5 +175,9 @@ int main() {
     run<11>("s_add dep chain", 64, dout, dcyc);
     run<12>("s_add / v_add alternating", 64, dout, dcyc);
     run<13>("s_cmp, branch(not taken), v_add, s_add", 64, dout, dcyc);
+    run<16>("VOP3, 3 sources in one VGPR bank", 64, dout, dcyc);
+    run<17>("VOP3, 3 sources in 3 VGPR banks", 64, dout, dcyc);
+    run<14>("sweep step R=3 (16 instr, chain 10)", 16 * 16, dout, dcyc);
+    run<15>("sweep step R=3 short chain (19 instr, chain 7)", 16 * 19, dout, dcyc);
     return 0;
 }
