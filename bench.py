@@ -180,7 +180,7 @@ def main():
         issue = None
         try:
             ipp = json.load(open(tf)).get("sweep_insts_per_pair_headline") if os.path.exists(tf) else None
-            if ipp and (m, args.ref_len) == (150, 2000) and args.mode in (None, 1) and fill_avg_s > 0:
+            if ipp and (m, args.ref_len, len(refs), len(reads)) == (150, 2000, 1000, 1) and args.mode in (None, 1) and fill_avg_s > 0:
                 insts = (ipp["valu"] + ipp["salu"]) * len(refs) * len(reads)
                 peak = 1024 * 2.4e9 / 4.45           # SIMDs x max clock / cycles per instruction of ONE wave per SIMD (tools/ubench.hip)
                 issue = {"insts_per_launch": insts, "achieved_ginst_s": round(insts / fill_avg_s / 1e9, 1),

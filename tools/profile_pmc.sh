@@ -4,7 +4,7 @@
 #   dword-store / dword-load calibration kernels for FETCH_SIZE / WRITE_SIZE.
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$R/gpurun_out/pmc
+OUT=$R/gpurun_out/pmc; rm -rf $OUT
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 hipcc --offload-arch=gfx950 -O3 $R/tools/pmc_calib.hip -o /tmp/pmc_calib || exit 1
