@@ -3,8 +3,9 @@
 //
 //   seqw   uint32[]   every sequence as a BYTE image: 1 canonical code per base, 4 per dword, image start
 //                     16-byte aligned.  Codes: A,C,G,T (any case) -> 0,8,16,24 -- the bit offset of the
-//                     base's entry in a row's 4 x int8 score profile, so the fill kernel's lookup is one
-//                     v_bfe_i32 -- every other (upper-cased) byte value -> a distinct code outside that set.
+//                     base's entry in a row's 4 x int8 score profile: the sweep turns a code into the one-hot
+//                     word 1 << code with one SDWA shift and looks the score up with v_dot4_i32_i8 -- every
+//                     other (upper-cased) byte value -> a distinct code outside that set.
 //                     Each image is followed by SWMI_SEQ_PAD_WORDS zero dwords so a 16-step block may
 //                     over-read past the end.
 //   refs / reads      SeqDesc per sequence.

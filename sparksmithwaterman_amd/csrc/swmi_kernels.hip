@@ -374,7 +374,7 @@ __device__ __forceinline__ StripGeom strip_geom(uint32_t m, uint32_t n, uint32_t
 
 // ------------------------------------------------------------------------------------------------
 // fill: one pair, one wavefront.  R rows per lane; ACGT = both sequences pure ACGT and scores fit a
-// signed byte (profile lookup by v_bfe_i32 instead of compare+select); STRICT = DistributedSW tie order;
+// signed byte (profile lookup by v_dot4_i32_i8 instead of compare+select); STRICT = DistributedSW tie order;
 // MULTI = more than one strip of 64*R rows (seam rows through memory); MODE = FIELD or SCORE.
 // ------------------------------------------------------------------------------------------------
 // PIPE (mode 1, MULTI): this wavefront sweeps only strip `my_strip`; the wavefront of strip s-1 runs a few blocks ahead
