@@ -256,17 +256,19 @@ extern "C" int swmi_set_option(swmi_ctx *ctx, const char *name, int64_t value) {
 // sequence encoding
 // ------------------------------------------------------------------------------------------
 // Canonical base codes: Character.toUpperCase restricted to ISO-8859-1 input (SmithWaterman.java:311-312:
-// a-z and 0xE0-0xFE except 0xF7 drop 0x20; 0xB5 and 0xFF map outside Latin-1 and only equal themselves) followed by a permutation of the byte values that puts A,C,G,T on
-// the codes 0,8,16,24 (their bit offsets in a 4 x int8 score profile), so that
-// code(x) == code(y)  <=>  toUpperCase(x) == toUpperCase(y).
+// a-z and 0xE0-0xFE except 0xF7 drop 0x20; 0xB5 and 0xFF map outside Latin-1 and only equal themselves) followed by a permutation of the byte values that puts the eight
+// "fast" symbols A,C,G,T,N,U,R,Y on the codes 0,4,...,28 (their bit offsets in an 8 x int4 score profile), so that
+// code(x) == code(y)  <=>  toUpperCase(x) == toUpperCase(y).  Sequences made of those symbols only (and scores within
+// int4) run the v_dot8_i32_i4 cell stream -- a reference with N stretches stays on the fast path; any other byte alphabet
+// runs the compare-and-select variant.
 static const uint8_t *code_table() {
     static uint8_t T[256];
     static bool init = false;
     if (!init) {
         uint8_t perm[256];
         for (int i = 0; i < 256; i++) perm[i] = (uint8_t)i;
-        const uint8_t acgt[4] = {'A', 'C', 'G', 'T'};
-        for (int k = 0; k < 4; k++) std::swap(perm[acgt[k]], perm[8 * k]);   // A,C,G,T -> 0,8,16,24
+        const uint8_t fast[8] = {'A', 'C', 'G', 'T', 'N', 'U', 'R', 'Y'};
+        for (int k = 0; k < 8; k++) std::swap(perm[fast[k]], perm[4 * k]);   // -> 0,4,...,28
         for (int i = 0; i < 256; i++) {
             int u = i;
             if ((i >= 'a' && i <= 'z') || (i >= 0xE0 && i <= 0xFE && i != 0xF7)) u = i - 32;
@@ -294,7 +296,7 @@ static void encode_sequences(const uint8_t *bytes, const uint64_t *off, uint32_t
         uint32_t *bwp = seqw.data() + d.boff;
         for (uint64_t k = 0; k < len; k++) {
             const uint32_t c = T[p[k]];
-            acgt &= (c & 0xE7u) == 0;                               // 0, 8, 16 or 24
+            acgt &= (c & 0xE3u) == 0;                               // 0, 4, ..., 28
             bwp[k >> 2] |= c << (8 * (k & 3));
         }
         d.acgt = acgt ? 1u : 0u;

@@ -2,10 +2,10 @@
 // (swmi_kernels.hip).  HBM data layout of one batch:
 //
 //   seqw   uint32[]   every sequence as a BYTE image: 1 canonical code per base, 4 per dword, image start
-//                     16-byte aligned.  Codes: A,C,G,T (any case) -> 0,8,16,24 -- the bit offset of the
-//                     base's entry in a row's 4 x int8 score profile: the sweep turns a code into the one-hot
-//                     word 1 << code with one SDWA shift and looks the score up with v_dot4_i32_i8 -- every
-//                     other (upper-cased) byte value -> a distinct code outside that set.
+//                     16-byte aligned.  Codes: the eight fast symbols A,C,G,T,N,U,R,Y (any case) -> 0,4,...,28 --
+//                     the bit offset of the symbol's entry in a row's 8 x int4 score profile: the sweep turns a
+//                     code into the one-hot word 1 << code with one SDWA shift and looks the score up with
+//                     v_dot8_i32_i4 -- every other (upper-cased) byte value -> a distinct code outside that set.
 //                     Each image is followed by SWMI_SEQ_PAD_WORDS zero dwords so a 16-step block may
 //                     over-read past the end.
 //   refs / reads      SeqDesc per sequence.
@@ -46,7 +46,7 @@
 struct SeqDesc {
     uint32_t len;     // bases
     uint32_t boff;    // dword offset of the byte image in seqw (multiple of 4)
-    uint32_t acgt;    // 1 if every base is A/C/G/T (codes 0,8,16,24)
+    uint32_t acgt;    // 1 if every base is one of the eight fast symbols (codes 0,4,...,28)
     uint32_t pad;
 };
 

@@ -79,6 +79,9 @@ __device__ __forceinline__ uint32_t seq_code(const uint32_t *__restrict__ w, uin
 // ------------------------------------------------------------------------------------------------
 // the R cells of one lane in one step (previous column's H in hin, this column's H to hout)
 // ------------------------------------------------------------------------------------------------
+// the fast cell stream looks scores up in a profile of 8 x int4 (v_dot8_i32_i4): match and mismatch must fit
+#define SWMI_SCORES_FIT(A) ((A).match >= -8 && (A).match <= 7 && (A).mismatch >= -8 && (A).mismatch <= 7)
+
 #include "swmi_cells_gen.inc"   // CellsAsm<R, ACGT, STRICT, DIRS>: hand-scheduled instruction stream
 
 // Plain C++ statement of the same update (build with -DSWMI_NO_ASM to A/B against the asm stream).
@@ -90,7 +93,7 @@ struct CellsRef {
         for (int k = 0; k < R; ++k) {
             const int left = hin[k];
             int sc;
-            if (ACGT) sc = rb ? __builtin_amdgcn_sbfe(q[k], (unsigned)__builtin_ctz((unsigned)rb), 8u) : 0;   // rb = 1 << 8*base
+            if (ACGT) sc = rb ? __builtin_amdgcn_sbfe(q[k], (unsigned)__builtin_ctz((unsigned)rb), 4u) : 0;   // rb = 1 << 4*symbol
             else      sc = (rb == q[k]) ? vmat : vmis;
             const int a = diag + sc;                       // SmithWaterman.java:244 / AlignmentScore :309-318
             const int t2 = (up > left ? up : left) + gap;   // :227, :235 (InsDelScore :277-280)
@@ -174,7 +177,7 @@ struct FillState {
     int h[R];            // H of the lane's rows: read by even steps of a block, written by odd ones
     int g[R];            // ... and the other way round (ping-pong, see fill_block16)
     uint32_t acc[R];     // direction bits of the last <= 16 steps
-    int q[R];            // ACGT: the row's 4 x int8 score profile; else the read's base code
+    int q[R];            // ACGT (= fast symbols): the row's 8 x int4 score profile; else the read's base code
     int nprev, rb;
     int thr;             // wave-uniform running maximum
     uint32_t cnt;        // wave-uniform number of cells equal to thr
@@ -191,11 +194,11 @@ __device__ __forceinline__ void setup_rows(FillState<R> &S, const uint32_t *__re
 #pragma unroll
     for (int k = 0; k < R; ++k) {
         const uint32_t row = row0 + k;
-        if (ACGT) {                                   // 4 signed score bytes indexed by the reference code
-            uint32_t p = (uint32_t)(mismatch & 0xFF) * 0x01010101u;
+        if (ACGT) {                                   // 8 signed score nibbles indexed by the reference code
+            uint32_t p = (uint32_t)(mismatch & 0xF) * 0x11111111u;
             if (row < m) {
-                const uint32_t c = seq_code(readw, row);      // 0, 8, 16 or 24
-                p = (p & ~(0xFFu << c)) | ((uint32_t)(match & 0xFF) << c);
+                const uint32_t c = seq_code(readw, row);      // 0, 4, ..., 28
+                p = (p & ~(0xFu << c)) | ((uint32_t)(match & 0xF) << c);
             }
             S.q[k] = (int)p;
         } else {
@@ -251,8 +254,8 @@ __device__ __forceinline__ void fill_block16(FillState<R> &S, const uint4 w, con
         const int (&hin)[R] = (s & 1u) ? S.g : S.h;
         int (&hout)[R] = (s & 1u) ? S.h : S.g;
         const uint32_t wsel = s < 4 ? w.x : s < 8 ? w.y : s < 12 ? w.z : w.w;
-        // base code of column t0+s+1 (lane 0).  ACGT: codes are 0, 8, 16, 24 and travel down the lanes ONE-HOT
-        // (1 << code) so that one v_dot4_i32_i8 with the row's score profile yields NW + s(ref, read); the SDWA byte
+        // base code of column t0+s+1 (lane 0).  ACGT: codes are 0, 4, ..., 28 and travel down the lanes ONE-HOT
+        // (1 << code) so that one v_dot8_i32_i4 with the row's score profile yields NW + s(ref, read); the SDWA byte
         // select makes extract + shift a single instruction.
         int feed;
         if (ACGT) {
@@ -373,8 +376,9 @@ __device__ __forceinline__ StripGeom strip_geom(uint32_t m, uint32_t n, uint32_t
 }
 
 // ------------------------------------------------------------------------------------------------
-// fill: one pair, one wavefront.  R rows per lane; ACGT = both sequences pure ACGT and scores fit a
-// signed byte (profile lookup by v_dot4_i32_i8 instead of compare+select); STRICT = DistributedSW tie order;
+// fill: one pair, one wavefront.  R rows per lane; ACGT = both sequences made of the eight fast symbols
+// (A,C,G,T,N,U,R,Y -- the template parameter kept its first name) and match/mismatch fit a
+// signed nibble (profile lookup by v_dot8_i32_i4 instead of compare+select); STRICT = DistributedSW tie order;
 // MULTI = more than one strip of 64*R rows (seam rows through memory); MODE = FIELD or SCORE.
 // ------------------------------------------------------------------------------------------------
 // PIPE (mode 1, MULTI): this wavefront sweeps only strip `my_strip`; the wavefront of strip s-1 runs a few blocks ahead
@@ -569,7 +573,7 @@ __device__ __forceinline__ void fill_entry(const FillArgs &A) {
     if (MODE == SWMI_MODE_WINMAX && A.skip_multi && qd.len > WAVE * SWMI_RMAX) return;   // swept strip by strip, see below
     // profile lookup needs both sequences pure ACGT and scores that fit a signed byte
     const bool acgt = rd.acgt && qd.acgt &&
-                      A.match >= -128 && A.match <= 127 && A.mismatch >= -128 && A.mismatch <= 127;
+                      SWMI_SCORES_FIT(A);
     if (MODE == SWMI_MODE_SCORE || MODE == SWMI_MODE_WINMAX) {   // scores do not depend on the tie order
         if (acgt) fill_dispatch<true, false, MODE>(A, pd, lane, qd.len);
         else      fill_dispatch<false, false, MODE>(A, pd, lane, qd.len);
@@ -603,7 +607,7 @@ sw_sweep_winmax_strips_kernel(const FillArgs A) {
     const SeqDesc rd = A.refs[pd.ref_id];
     const SeqDesc qd = A.reads[pd.read_id];
     const bool acgt = rd.acgt && qd.acgt &&
-                      A.match >= -128 && A.match <= 127 && A.mismatch >= -128 && A.mismatch <= 127;
+                      SWMI_SCORES_FIT(A);
     if (acgt) fill_pair<SWMI_RMAX, true, false, true, SWMI_MODE_WINMAX, true>(A, pd, lane, it.y);
     else      fill_pair<SWMI_RMAX, false, false, true, SWMI_MODE_WINMAX, true>(A, pd, lane, it.y);
 }
@@ -705,7 +709,7 @@ __device__ __forceinline__ uint32_t replay_dispatch(const TraceArgs &A, const Pa
 
 // true for the pairs the full-featured mode-1 traceback handles: pure ACGT with int8 scores, the serial tie order
 __device__ __forceinline__ bool swmi_common_pair(const TraceArgs &A, const SeqDesc rd, const SeqDesc qd) {
-    return rd.acgt && qd.acgt && A.match >= -128 && A.match <= 127 && A.mismatch >= -128 && A.mismatch <= 127 && !A.strict;
+    return rd.acgt && qd.acgt && SWMI_SCORES_FIT(A) && !A.strict;
 }
 
 // re-sweeps one window.  FULL: any variant (byte alphabet, DistributedSW tie order, several strips); otherwise only the
@@ -741,7 +745,7 @@ __device__ __forceinline__ uint32_t detect_cells(const TraceArgs &A, const PairD
     const uint32_t *__restrict__ refw = A.seqw + rd.boff;
     const uint32_t *__restrict__ readw = A.seqw + qd.boff;
     const StripGeom G = strip_geom<R>(m, n, 1u);
-    const bool acgt = rd.acgt && qd.acgt && A.match >= -128 && A.match <= 127 && A.mismatch >= -128 && A.mismatch <= 127;
+    const bool acgt = rd.acgt && qd.acgt && SWMI_SCORES_FIT(A);
     const uint64_t cbase = A.cells_off ? A.cells_off[pd.out_id] : (uint64_t)pd.out_id * A.cell_cap;
     const uint32_t ccap = A.cells_cap ? A.cells_cap[pd.out_id] : A.cell_cap;
     uint2 *__restrict__ cells = const_cast<uint2 *>(A.cells) + cbase;
@@ -787,7 +791,7 @@ __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDes
     const int dec0 = A.match > A.mismatch ? A.match : A.mismatch;
     const uint32_t udec = dec0 > 0 ? (uint32_t)dec0 : 0u;    // the most one alignment move can lower the tracked score
     const uint32_t ugdec = A.gap > 0 ? (uint32_t)A.gap : 0u;  // ... and one gap move
-    const bool acgt = rd.acgt && qd.acgt && A.match >= -128 && A.match <= 127 && A.mismatch >= -128 && A.mismatch <= 127;
+    const bool acgt = rd.acgt && qd.acgt && SWMI_SCORES_FIT(A);
 
     uint32_t *lds_ops = lds;                                   // [A.lds_words]      one op per BYTE, staged per alignment
     uint32_t *lds_read = lds_ops + A.lds_words;                // [A.lds_read_words] the read's codes
@@ -1056,7 +1060,7 @@ __device__ __forceinline__ void coop_helper(const TraceArgs &A, const PairDesc p
     const uint32_t *__restrict__ refw = A.seqw + rd.boff;
     const uint32_t *__restrict__ readw = A.seqw + qd.boff;
     const StripGeom G = strip_geom<R>(m, n, 1u);
-    const bool acgt = rd.acgt && qd.acgt && A.match >= -128 && A.match <= 127 && A.mismatch >= -128 && A.mismatch <= 127;
+    const bool acgt = rd.acgt && qd.acgt && SWMI_SCORES_FIT(A);
     const uint32_t team = (wave - nw) % nw, q = 1u + (wave - nw) / nw;
     uint32_t *__restrict__ tile = tiles + (team * ts + q) * (SWMI_CK_BLOCKS * SWMI_RMAX * WAVE) ;
     (void)tile;
@@ -1117,7 +1121,7 @@ __device__ __forceinline__ uint32_t winmax_detect(const TraceArgs &A, const Pair
     const uint32_t n = rd.len, m = qd.len;
     const uint32_t *__restrict__ refw = A.seqw + rd.boff;
     const uint32_t *__restrict__ readw = A.seqw + qd.boff;
-    const bool acgt = rd.acgt && qd.acgt && A.match >= -128 && A.match <= 127 && A.mismatch >= -128 && A.mismatch <= 127;
+    const bool acgt = rd.acgt && qd.acgt && SWMI_SCORES_FIT(A);
     const StripGeom G = strip_geom<R>(m, n, 1u);
     constexpr uint32_t WIN_WORDS = SWMI_CK_BLOCKS * SWMI_RMAX * WAVE;
     uint32_t ncand = 0, gc[SWMI_TB_SLOTS] = {0u, 0u, 0u, 0u};

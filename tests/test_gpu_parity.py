@@ -289,3 +289,18 @@ def test_long_reads_mixed_with_short_ones(ctx):
     reads = [cut(refs[0], 700), cut(refs[1], 150), cut(refs[2], 300, "ACGTN", 7), cut(refs[0], 257, every=5)]
     for tie in (0, 1):
         check_batch(ctx, refs, reads, tie=tie)
+
+
+def test_fast_symbols_and_int4_score_bounds(ctx):
+    """The fast cell stream covers the symbols A,C,G,T,N,U,R,Y (any case) with match/mismatch inside int4; one step outside
+    either (another letter, match = 8, mismatch = -9) must take the compare-and-select variant and agree as well."""
+    rng = random.Random(99)
+
+    def seqs(alphabet, n, lens):
+        return ["".join(rng.choice(alphabet) for _ in range(rng.choice(lens))) for _ in range(n)]
+
+    refs = seqs("ACGTN", 6, (90, 300, 700)) + seqs("acgtnURY", 3, (200, 333))
+    reads = seqs("ACGTN", 2, (40, 150)) + seqs("ACGTUY", 1, (300,))
+    for scores in ((5, -3, -4), (7, -8, -2), (1, -1, -1), (8, -3, -4), (5, -9, -4)):
+        check_batch(ctx, refs, reads, scores=scores)
+    check_batch(ctx, refs + seqs("ACGTNK", 2, (120,)), reads, tie=1)      # K is not a fast symbol

@@ -3,8 +3,8 @@
 stream that updates the R cells a lane owns in one anti-diagonal step of the fill kernel.
 
 Per cell (ACGT variant) 8 VALU instructions:
-    v_dot4_i32_i8 a, q, rb, diag         a = NW + s(ref,read): rb is the reference base one-hot (1 << 8*base), q the
-                                         row's 4 x int8 score profile, the accumulator operand the diagonal neighbour
+    v_dot8_i32_i4 a, q, rb, diag         a = NW + s(ref,read): rb is the reference symbol one-hot (1 << 4*symbol), q the
+                                         row's 8 x int4 score profile, the accumulator operand the diagonal neighbour
     v_cmp_ge_i32  sI, up, left           insertion beats deletion?   (v_cmp_gt for the DistributedSW order)
     v_max_i32     t, up, left
     v_add_u32     t, gap, t              t = max(N, W) + gap
@@ -41,10 +41,10 @@ def schedule(R, acgt, strict, dirs=True):
     def nw(k):
         return "%[diag]" if k == 0 else f"%[i{k-1}]"
     if acgt:
-        # rb is the reference base ONE-HOT (1 << 8*base): the dot product with the row's 4 x int8 score profile
+        # rb is the reference symbol ONE-HOT (1 << 4*symbol): the dot product with the row's 8 x int4 score profile
         # picks s(ref, read), and the accumulator operand adds the diagonal neighbour in the same instruction
         for k in range(R):
-            ins.append(Ins(f"v_dot4_i32_i8 %[a{k}], %[q{k}], %[rb], {nw(k)}", dot=[f"a{k}"]))
+            ins.append(Ins(f"v_dot8_i32_i4 %[a{k}], %[q{k}], %[rb], {nw(k)}", dot=[f"a{k}"]))
     else:
         for k in range(R):
             ins.append(Ins(f"v_cmp_eq_u32_e64 %[m{k}], %[rb], %[q{k}]", wr=[f"m{k}"]))
@@ -66,7 +66,7 @@ def schedule(R, acgt, strict, dirs=True):
                           Ins(f"v_max3_i32 %[o{k}], %[a{k}], %[t], 0")])
         if INTERLEAVE and acgt:
             # ins currently holds: bfe x R, add x R.  Rebuild: row 0 lookup first, then weave.
-            look = [[Ins(f"v_dot4_i32_i8 %[a{k}], %[q{k}], %[rb], {nw(k)}", dot=[f"a{k}"])] for k in range(R)]
+            look = [[Ins(f"v_dot8_i32_i4 %[a{k}], %[q{k}], %[rb], {nw(k)}", dot=[f"a{k}"])] for k in range(R)]
             ins = list(look[0])
             pending = [x for k in range(1, R) for x in look[k]]
             for k in range(R):

@@ -108,6 +108,8 @@ __global__ void __launch_bounds__(256) k(int *out, int iters, long long *cyc) {
                   [l0] "+v"(l0), [l1] "+v"(l1), [l2] "+v"(l2)
                 : [q] "v"(b), [gap] "v"(gp));
         }
+        if (V == 18) { asm volatile(REP16("v_dot8_i32_i4 %0, %4, %5, %0\n v_dot8_i32_i4 %1, %4, %5, %1\n v_dot8_i32_i4 %2, %4, %5, %2\n v_dot8_i32_i4 %3, %4, %5, %3\n")
+                                    : "+v"(a), "+v"(c), "+v"(d), "+v"(e) : "v"(b), "v"(f)); }
         if (V == 16) {     // VOP3 sources all in ONE VGPR bank (index % 4 equal)
             asm volatile(REP16("v_max3_i32 v40, v44, v48, v52\n v_max3_i32 v41, v45, v49, v53\n v_dot4_i32_i8 v42, v46, v50, v54\n v_max3_i32 v43, v47, v51, v55\n")
                          ::: "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55");
@@ -175,6 +177,7 @@ int main() {
     run<11>("s_add dep chain", 64, dout, dcyc);
     run<12>("s_add / v_add alternating", 64, dout, dcyc);
     run<13>("s_cmp, branch(not taken), v_add, s_add", 64, dout, dcyc);
+    run<18>("v_dot8_i32_i4 4 chains", 64, dout, dcyc);
     run<16>("VOP3, 3 sources in one VGPR bank", 64, dout, dcyc);
     run<17>("VOP3, 3 sources in 3 VGPR banks", 64, dout, dcyc);
     run<14>("sweep step R=3 (16 instr, chain 10)", 16 * 16, dout, dcyc);
