@@ -767,12 +767,14 @@ __device__ __forceinline__ uint32_t detect_cells(const TraceArgs &A, const PairD
     return cnt;
 }
 
-// COOP (mode 1): the workgroup's SWMI_TB_WAVES waves form `nslots` teams of `ts` waves, one walker (this function)
-// plus ts-1 helpers (coop_helper below) each.  Instead of re-sweeping one 32-step window at a time, the walker
-// publishes a request for up to ts consecutive windows, the team re-sweeps them in parallel into the team's tile,
-// and the walker then crosses the whole 32*ts-step span without stopping.  All waves of the workgroup move in
-// rounds delimited by two barriers: (A) requests published, (B) tiles complete.
-// shared[]: [0] number of maximum cells, [1] walkers finished, [4+4t ..] team t's request {strip, first block, windows}.
+// COOP (mode 1): the workgroup's waves form `nslots` teams of `ts` waves, one walker (this function) plus ts-1
+// helpers (coop_helper below) each.  Instead of re-sweeping one 32-step window at a time, the walker publishes a
+// request for up to ts consecutive windows, the team re-sweeps them in parallel into the team's tile, and the walker
+// then crosses the whole 32*ts-step span without stopping.  The teams of a workgroup run independently of each other:
+// a request is a sequence number in LDS the helpers poll (s_sleep between polls), completion a counter the walker polls;
+// there is no workgroup barrier after the cell list.
+// shared[]: [0] number of maximum cells, [4+4t ..] team t's request {strip, first block, windows, sequence number
+// (~0: the walker is done)}, [20+t] windows team t's helpers have delivered so far.
 template <int R, int TMODE, bool COOP, bool FULL = true>
 __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDesc pd, const PairOut po,
                                                const uint32_t lane, const uint32_t slot, const uint32_t nslots,
@@ -799,6 +801,7 @@ __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDes
     uint8_t *ops_b = reinterpret_cast<uint8_t *>(lds_ops);
     const uint8_t *read_b = reinterpret_cast<const uint8_t *>(lds_read);
     const uint8_t *ref_b = reinterpret_cast<const uint8_t *>(lds_ref);
+    uint32_t req_seq = 0, req_expected = 0;                    // COOP: requests published / windows expected back so far
 
     const unsigned long long tk0 = A.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
     unsigned long long tk_walk = 0, n_steps = 0, n_iters = 0;
@@ -873,17 +876,26 @@ __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDes
                         for (uint32_t x = 0; x < nb * R; ++x) lds_tile[x * WAVE + lane] = src[(uint64_t)x * WAVE];
                     } else {
                         if (COOP) {
-                            if (lane == 0) { shared[4u + 4u * slot] = s; shared[5u + 4u * slot] = wlo; shared[6u + 4u * slot] = nb / SWMI_CK_BLOCKS; }
-                            __syncthreads();                                       // (A) request visible to the helpers
+                            const uint32_t nq = nb / SWMI_CK_BLOCKS;
+                            ++req_seq;
+                            req_expected += nq - 1u;                               // helpers 1 .. nq-1 deliver one window each
+                            if (lane == 0) {
+                                shared[4u + 4u * slot] = s; shared[5u + 4u * slot] = wlo; shared[6u + 4u * slot] = nq;
+                                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                                __hip_atomic_store(const_cast<uint32_t *>(&shared[7u + 4u * slot]), req_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            }
                         }
                         (void)replay_any<R, false, FULL>(A, pd, n, m, acgt, refw, readw, G, s, wlo, lane, lds_tile, 0, 0u, nullptr, 0u);
                     }
                     lds_ref[lane] = rv0;
                     if (lane + WAVE < SWMI_TB_REFWIN_WORDS) lds_ref[lane + WAVE] = rv1;
                     if (COOP) {
-                        __syncthreads();                                           // (B) every wave's window is in the tile
-                        if (lane == 0) shared[6u + 4u * slot] = 0u;                // request served
-                    } else WAVE_SYNC();
+                        // wait for the helpers' windows
+                        while (__hip_atomic_load(const_cast<uint32_t *>(&shared[20u + slot]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < req_expected)
+                            __builtin_amdgcn_s_sleep(1);
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    }
+                    WAVE_SYNC();
                 }
                 const int tmin = (int)(16u * wlo);
                 const unsigned long long tw0 = A.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -1032,15 +1044,8 @@ __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDes
             WAVE_SYNC();
         }
     }
-    if (COOP) {
-        // finished: keep in step with the rounds of the teams still walking
-        if (lane == 0) atomicAdd(const_cast<uint32_t *>(&shared[1]), 1u);
-        for (;;) {
-            __syncthreads();                                                       // (A)
-            if (shared[1] == nslots) break;
-            __syncthreads();                                                       // (B)
-        }
-    }
+    if (COOP && lane == 0)                                                         // releases this team's helpers
+        __hip_atomic_store(const_cast<uint32_t *>(&shared[7u + 4u * slot]), 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (A.dbg && lane == 0 && slot == 0) {
         A.dbg[4 * pd.out_id] = __builtin_amdgcn_s_memtime() - tk0;
         A.dbg[4 * pd.out_id + 1] = tk_walk;
@@ -1064,15 +1069,22 @@ __device__ __forceinline__ void coop_helper(const TraceArgs &A, const PairDesc p
     const uint32_t team = (wave - nw) % nw, q = 1u + (wave - nw) / nw;
     uint32_t *__restrict__ tile = tiles + (team * ts + q) * (SWMI_CK_BLOCKS * SWMI_RMAX * WAVE) ;
     (void)tile;
+    uint32_t last = 0;
     for (;;) {
-        __syncthreads();                                                           // (A)
-        if (shared[1] == nw) break;
+        uint32_t seq;
+        while ((seq = __hip_atomic_load(const_cast<uint32_t *>(&shared[7u + 4u * team]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == last)
+            __builtin_amdgcn_s_sleep(2);
+        if (seq == 0xFFFFFFFFu) break;
+        last = seq;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         const uint32_t s = shared[4u + 4u * team], wlo = shared[5u + 4u * team], nq = shared[6u + 4u * team];
-        if (q < ts && q < nq)
+        if (q < ts && q < nq) {
             (void)replay_any<R, false, false>(A, pd, n, m, acgt, refw, readw, G, s, wlo + q * SWMI_CK_BLOCKS, lane,
                                        tiles + team * ts * (SWMI_CK_BLOCKS * SWMI_RMAX * WAVE) + q * SWMI_CK_BLOCKS * R * WAVE,
                                        0, 0u, nullptr, 0u);
-        __syncthreads();                                                           // (B)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) atomicAdd(const_cast<uint32_t *>(&shared[20u + team]), 1u);
+        }
     }
 }
 
@@ -1152,10 +1164,9 @@ __device__ __forceinline__ uint32_t winmax_detect(const TraceArgs &A, const Pair
             A.out[pd.out_id] = po;
             if (A.out_host) A.out_host[pd.out_id] = po;
             shared[0] = cnt;
-            shared[1] = 0u;
             shared[3] = staged;
         }
-        if (lane < SWMI_TB_SLOTS) shared[6u + 4u * lane] = 0u;
+        if (lane < SWMI_TB_SLOTS) { shared[7u + 4u * lane] = 0u; shared[20u + lane] = 0u; }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the cell list has left the CU before the others read it
     };
     const uint64_t cbase = A.cells_off ? A.cells_off[pd.out_id] : (uint64_t)pd.out_id * A.cell_cap;
