@@ -804,7 +804,7 @@ __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDes
     uint32_t req_seq = 0, req_expected = 0;                    // COOP: requests published / windows expected back so far
 
     const unsigned long long tk0 = A.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
-    unsigned long long tk_walk = 0, n_steps = 0, n_iters = 0;
+    unsigned long long tk_walk = 0, tk_stage = 0, n_steps = 0, n_iters = 0;
     if (!read_staged)
         for (uint32_t w = lane; w < (m + 3u) / 4u; w += WAVE) lds_read[w] = readw[w];
 
@@ -841,6 +841,7 @@ __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDes
             uint32_t n_ops = 0;
             int begin = 0;
             while ((int)score > 0 && i != 0u && j != 0u) {     // (a positive score at row/column 0 cannot happen with consistent
+                const unsigned long long ts0 = A.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
                                                                //  data; the test keeps a corrupted workspace from walking off the matrix)
                 // ---- stage the window that holds the current cell's step ----
                 const uint32_t s = (i - 1u) / rps;
@@ -899,6 +900,7 @@ __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDes
                 }
                 const int tmin = (int)(16u * wlo);
                 const unsigned long long tw0 = A.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
+                if (A.dbg) tk_stage += tw0 - ts0;
 
                 // Three diagonals are inspected at once, 21 lanes each: group 0 runs up from the current cell, group 1
                 // from the cell above it (where an insertion leads), group 2 from the cell to its left (a deletion).
@@ -1049,7 +1051,7 @@ __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDes
     if (A.dbg && lane == 0 && slot == 0) {
         A.dbg[4 * pd.out_id] = __builtin_amdgcn_s_memtime() - tk0;
         A.dbg[4 * pd.out_id + 1] = tk_walk;
-        A.dbg[4 * pd.out_id + 2] = n_steps;
+        A.dbg[4 * pd.out_id + 2] = n_steps | (tk_stage << 16);       // (steps < 65536 in the diagnostics runs)
         A.dbg[4 * pd.out_id + 3] = n_iters;
     }
 }
