@@ -1,7 +1,7 @@
 """One long pair (default 8000 x 8000) through every pipeline, checked against the oracle (GPU box).  Test helper for
 the LDS budget of the traceback kernels; not part of the product."""
 import os, sys, time, random
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT") or os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import sparksmithwaterman_amd as sw
 from oracle import sw_oracle as orc
 

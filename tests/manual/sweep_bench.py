@@ -4,14 +4,14 @@
 CPU oracle timed beside it on the small points.  References are REF repeated (EngineerData.java:118), so tied
 maxima -- and therefore the multi-alignment output path -- are the norm, exactly as in the reference's data.
 
-    python tools/sweep_bench.py [--quick] > gpurun_out/sweeps.md
+    python tests/manual/sweep_bench.py [--quick] > gpurun_out/sweeps.md
 """
 import argparse
 import os
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 
 REF = "CCTGGGTCCTGCCTCGCATCTGACCAGGGCAGGTGGCCTCCTCATCACACTGCTGCCTCTGCTGTTGGCCCTGCTCATGA"       # EngineerData.java:23
 READ_80 = "AATTTTAGTCTCTCCCTACCCTTTTGGACAGAGCTTCCTGTCCTCTCATTTCACAGGTTATGCAACAGAGGGTTCTGTGT"   # :26
