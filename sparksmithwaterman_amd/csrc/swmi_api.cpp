@@ -636,14 +636,14 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
             HIP_TRY(hipMemcpy(d.data(), ta.dbg, np * 32, hipMemcpyDeviceToHost));
             double a0 = 0, a1 = 0, a2 = 0, a3 = 0; unsigned long long mx = 0;
             double a4 = 0;
-            for (size_t k = 0; k < np; k++) { a0 += d[4*k]; a1 += d[4*k+1]; a2 += d[4*k+2] & 0xFFFF; a4 += d[4*k+2] >> 16; a3 += d[4*k+3]; mx = std::max(mx, d[4*k]); }
+            for (size_t k = 0; k < np; k++) { a0 += d[4*k]; a1 += d[4*k+1] & 0xFFFFFFFFull; a2 += d[4*k+2] & 0xFFFF; a4 += d[4*k+2] >> 16; a3 += d[4*k+3] & 0xFFFFFFFFull; mx = std::max(mx, d[4*k]); }
             fprintf(stderr, "[swmi tb dbg] wave ticks mean=%.0f max=%llu; walk ticks mean=%.0f; staging ticks mean=%.0f; steps mean=%.1f; iterations mean=%.2f\n",
                     a0 / np, mx, a1 / np, a4 / np, a2 / np, a3 / np);
             const PairOut *po_dbg = (const PairOut *)((const uint8_t *)b->h_result.p + result_out_off());
             double cs[4] = {0, 0, 0, 0}, cw[4] = {0, 0, 0, 0}; unsigned long long cm[4] = {0, 0, 0, 0}; size_t cn[4] = {0, 0, 0, 0};
             for (size_t k = 0; k < np; k++) {
                 const size_t c = std::min<uint64_t>(po_dbg[k].n_cells, 4) - (po_dbg[k].n_cells ? 1 : 0);
-                cs[c] += d[4 * k]; cw[c] += d[4 * k + 1]; cm[c] = std::max(cm[c], d[4 * k]); cn[c]++;
+                cs[c] += d[4 * k]; cw[c] += d[4 * k + 1] & 0xFFFFFFFFull; cm[c] = std::max(cm[c], d[4 * k]); cn[c]++;
             }
             {   // the slowest pairs: what makes the launch's tail
                 std::vector<size_t> idx(np);
@@ -651,9 +651,11 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
                 const size_t top = std::min<size_t>(np, 6);
                 std::partial_sort(idx.begin(), idx.begin() + top, idx.end(), [&](size_t x, size_t y) { return d[4 * x] > d[4 * y]; });
                 for (size_t t = 0; t < top; t++)
-                    fprintf(stderr, "[swmi tb dbg]   slow pair %zu: ticks=%llu walk=%llu staging=%llu steps=%llu iterations=%llu alignments=%llu\n", idx[t],
-                            d[4 * idx[t]], d[4 * idx[t] + 1], d[4 * idx[t] + 2] >> 16, d[4 * idx[t] + 2] & 0xFFFF, d[4 * idx[t] + 3],
-                            (unsigned long long)po_dbg[idx[t]].n_cells);
+                    fprintf(stderr, "[swmi tb dbg]   slow pair %zu: ticks=%llu walk=%llu staging=%llu in %llu stagings, steps=%llu iterations=%llu alignments=%llu\n", idx[t],
+                            d[4 * idx[t]], d[4 * idx[t] + 1] & 0xFFFFFFFFull, d[4 * idx[t] + 2] >> 16, d[4 * idx[t] + 3] >> 32, d[4 * idx[t] + 2] & 0xFFFF,
+                            d[4 * idx[t] + 3] & 0xFFFFFFFFull, (unsigned long long)po_dbg[idx[t]].n_cells);
+                for (size_t t = 0; t < top; t++)
+                    fprintf(stderr, "[swmi tb dbg]     ... of the staging time of pair %zu, %llu ticks waiting for helpers\n", idx[t], d[4 * idx[t] + 1] >> 32);
             }
             for (int c = 0; c < 4; c++)
                 if (cn[c]) fprintf(stderr, "[swmi tb dbg]   %d%s alignment(s): %zu pairs, wave ticks mean=%.0f max=%llu, walk(slot 0) mean=%.0f\n",

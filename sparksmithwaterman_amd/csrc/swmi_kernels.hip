@@ -892,15 +892,17 @@ __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDes
                     if (lane + WAVE < SWMI_TB_REFWIN_WORDS) lds_ref[lane + WAVE] = rv1;
                     if (COOP) {
                         // wait for the helpers' windows
+                        const unsigned long long tq0 = A.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
                         while (__hip_atomic_load(const_cast<uint32_t *>(&shared[20u + slot]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < req_expected)
                             __builtin_amdgcn_s_sleep(1);
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                        if (A.dbg) tk_walk += (__builtin_amdgcn_s_memtime() - tq0) << 32;     // (waiting counted in the upper half)
                     }
                     WAVE_SYNC();
                 }
                 const int tmin = (int)(16u * wlo);
                 const unsigned long long tw0 = A.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
-                if (A.dbg) tk_stage += tw0 - ts0;
+                if (A.dbg) { tk_stage += tw0 - ts0; n_iters += 1ull << 32; }      // (stagings counted in the upper half)
 
                 // Three diagonals are inspected at once, 21 lanes each: group 0 runs up from the current cell, group 1
                 // from the cell above it (where an insertion leads), group 2 from the cell to its left (a deletion).
@@ -1244,6 +1246,7 @@ sw_traceback_winmax_kernel(const TraceArgs A) {
     extern __shared__ uint32_t wm_lds[];
     const uint32_t pair = blockIdx.x;
     if (pair >= A.n_pairs) return;
+    // (rotating the walker role over the hardware waves, in case wave w always landed on SIMD w, changes nothing)
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const PairDesc pd = A.pairs[pair];
     PairOut po = A.out[pd.out_id];
