@@ -102,6 +102,7 @@ struct swmi_ctx {
     uint64_t arena_words_per_pair = 48;     // first guess of the record arena, grows on demand
     uint64_t arena_copy_wpp = 48;           // arena words per pair fetched with the first D2H (tracks the last run)
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    PinnedBuf h_err;                        // one host-mapped word the kernels raise on an internal failure (strip pipeline timeout)
 };
 
 // one alignment as parsed from the arena
@@ -227,6 +228,8 @@ extern "C" int swmi_create(int device, swmi_ctx **out) {
         e = hipEventCreate(&ev);
         if (e != hipSuccess) return fail(SWMI_ERR_HIP, "hipEventCreate: %s", hipGetErrorString(e));
     }
+    { int r = c->h_err.reserve(64); if (r) return r; }
+    *(volatile uint32_t *)c->h_err.p = 0u;
     *out = c.release();
     return SWMI_OK;
 }
@@ -236,6 +239,7 @@ extern "C" void swmi_destroy(swmi_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     for (auto &ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    ctx->h_err.release();
     delete ctx;
 }
 
@@ -566,6 +570,7 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
         fa.strip_items = n_strip_items ? b->d_strip_items.as<uint2>() : nullptr;
         fa.progress = n_strip_items ? b->d_progress.as<uint32_t>() : nullptr;
         fa.n_strip_items = (uint32_t)n_strip_items;
+        fa.err_host = (uint32_t *)ctx->h_err.dp;
         fa.pad3 = 0;
 
         TraceArgs &ta = rs.ta;
@@ -623,6 +628,10 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
         const auto c1 = std::chrono::steady_clock::now();
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         const auto c2 = std::chrono::steady_clock::now();
+        if (*(volatile uint32_t *)ctx->h_err.p != 0u) {
+            *(volatile uint32_t *)ctx->h_err.p = 0u;
+            return fail(SWMI_ERR_HIP, "the strip pipeline of the sweep timed out waiting for a producer wavefront; results discarded");
+        }
         rs.enqueue_us += std::chrono::duration<double, std::micro>(c1 - c0).count();
         rs.wait_us += std::chrono::duration<double, std::micro>(c2 - c1).count();
         if (ctx->profiling) {

@@ -107,6 +107,7 @@ struct FillArgs {
     uint32_t       *progress;    // per strip item: 16-step blocks finished (the item's index is PairDesc.pad + strip)
     uint32_t        n_strip_items;
     uint32_t        pad3;
+    uint32_t       *err_host;    // host-mapped word, set to 1 when a strip gave up waiting for its producer
 };
 
 struct TraceArgs {

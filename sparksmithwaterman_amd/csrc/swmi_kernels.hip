@@ -460,7 +460,10 @@ __device__ __forceinline__ void fill_pair(const FillArgs &A, const PairDesc pd, 
                 uint32_t spins = 0;
                 while (!gave_up && __hip_atomic_load(progress + (s - 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
                     __builtin_amdgcn_s_sleep(8);
-                    if (++spins > (1u << 18)) gave_up = true;   // a producer that never comes (~60 ms): wrong results beat a hung GPU
+                    if (++spins > (1u << 18)) {                  // a producer that never comes (~60 ms): an error beats a hung GPU
+                        gave_up = true;
+                        if (lane == 0 && A.err_host) *A.err_host = 1u;         // the host discards the run (swmi_api.cpp)
+                    }
                 }
             }
             const uint32_t col = 16u * tb + 1u + (lane & 15u);
