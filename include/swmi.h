@@ -87,7 +87,8 @@ void        swmi_default_params(swmi_params *p);
  *                Needs mismatch <= 0 and gap <= 0; other scores run as mode 2.
  *   2            as 1, but tied maxima are tracked during the sweep (per-step test + rare handler).
  *   0            the sweep writes the whole 2-bit direction field to HBM and the traceback reads it
- *                (cheaper when most pairs have many tied maxima). */
+ *                (cheaper when most pairs have many tied maxima).  Batches with pairs longer than about
+ *                16 k bases (m + n) run as mode 1/2: mode 0's traceback tiles leave too little LDS for them. */
 int         swmi_set_option(swmi_ctx *ctx, const char *name, int64_t value);
 
 /* ---- staged path: upload once, run many times (what bench.py times) ------------- */

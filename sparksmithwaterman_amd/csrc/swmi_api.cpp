@@ -411,6 +411,26 @@ inline size_t result_arena_off(size_t np) { return (64 + np * sizeof(PairOut) + 
 
 }  // namespace
 
+// longest possible traceback of an n x m pair: A + I <= m rows, A + D <= n columns, and -- with match > 0 > gap -- the
+// score match*A + gap*(I + D) must stay positive (`while (score > 0)`), which caps the gap moves
+static uint64_t path_bound(uint64_t n_, uint64_t m_, const swmi_params &p) {
+    uint64_t path = n_ + m_;
+    if (p.match > 0 && p.gap < 0 && p.mismatch <= p.match) {
+        const uint64_t g = (uint64_t)(-(int64_t)p.gap), mt = (uint64_t)p.match;
+        path = std::min(path, std::min(m_ + std::min(n_, mt * m_ / g), n_ + std::min(m_, mt * n_ / g)));
+    }
+    return path;
+}
+
+// bytes of LDS a traceback workgroup needs for pairs whose longest path / read are given
+// (swmi_kernels.hip: SWMI_TB_BLOCKS = 16 blocks per mode-0 tile, SWMI_TB_WAVES = 8, SWMI_TB_REFWIN_WORDS = 96)
+static uint64_t traceback_lds_bytes(uint32_t mode, uint64_t max_path, uint64_t max_read) {
+    const uint64_t lds_words = (max_path + 3) / 4 + 1, lds_read_words = (max_read + 3) / 4 + 1;
+    const uint64_t win = (uint64_t)SWMI_RMAX * 64;
+    const uint64_t tile_words = mode == 0 ? 4ull * 16 * win : (mode == 1 ? 32 + 8ull * SWMI_CK_BLOCKS * win : 4ull * SWMI_CK_BLOCKS * win);
+    return 4ull * (tile_words + 4ull * (lds_words + lds_read_words + 96));
+}
+
 // Runs fill + traceback for `work` (already ordered), one chunk, and parses the records.
 // per-pair cell-list geometry: uniform (cap) when cells_cap_exact is empty, else exact per pair.
 static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, size_t hi,
@@ -453,17 +473,7 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
             for (uint32_t st = 0; st < strips; st++) strip_items.push_back(make_uint2((uint32_t)k, st));
         }
         pd[k] = d;
-        {
-            // longest possible traceback: A + I <= m rows, A + D <= n columns, and -- with match > 0 > gap -- the score
-            // match*A + gap*(I + D) must stay positive (`while (score > 0)`), which caps the gap moves
-            const uint64_t n_ = b->ref_desc[d.ref_id].len, m_ = b->read_desc[d.read_id].len;
-            uint64_t path = n_ + m_;
-            if (b->params.match > 0 && b->params.gap < 0 && b->params.mismatch <= b->params.match) {
-                const uint64_t g = (uint64_t)(-(int64_t)b->params.gap), mt = (uint64_t)b->params.match;
-                path = std::min(path, std::min(m_ + std::min(n_, mt * m_ / g), n_ + std::min(m_, mt * n_ / g)));
-            }
-            max_path = std::max<uint32_t>(max_path, (uint32_t)path);
-        }
+        max_path = std::max<uint32_t>(max_path, (uint32_t)path_bound(b->ref_desc[d.ref_id].len, b->read_desc[d.read_id].len, b->params));
         max_read = std::max(max_read, b->read_desc[d.read_id].len);
     }
     n_strip_items = strip_items.size();
@@ -518,11 +528,7 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
     {
         // the traceback stages one alignment's ops and the read per walker (4 per workgroup) next to its direction tiles:
         // 160 KB of LDS per workgroup bound the longest pair (m + n of about 16 k bases in mode 0, 24 k in modes 1/2)
-        // (swmi_kernels.hip: SWMI_TB_BLOCKS = 16 blocks per mode-0 tile, SWMI_TB_WAVES = 8, SWMI_TB_REFWIN_WORDS = 96)
-        const uint64_t win = (uint64_t)SWMI_RMAX * 64;
-        const uint64_t tile_words = b->eff_mode == 0 ? 4ull * 16 * win
-                                  : (b->eff_mode == 1 ? 32 + 8ull * SWMI_CK_BLOCKS * win : 4ull * SWMI_CK_BLOCKS * win);
-        const uint64_t need = 4ull * (tile_words + 4ull * ((uint64_t)lds_words + lds_read_words + 96));
+        const uint64_t need = traceback_lds_bytes(b->eff_mode, max_path, max_read);
         if (need > 160ull * 1024)
             return fail(SWMI_ERR_UNSUPPORTED, "a pair of %u bases in total needs %llu bytes of LDS for the traceback (limit 163840)",
                         max_path, (unsigned long long)need);
@@ -831,6 +837,15 @@ extern "C" int swmi_batch_run(swmi_ctx *ctx, swmi_batch *b, const swmi_params *p
     // The schedule only depends on the sequence lengths and the pipeline mode: built once per batch.
     // mode 1 needs pad rows that cannot outgrow the real cells they derive from: mismatch <= 0 and gap <= 0
     b->eff_mode = (ctx->mode == 1 && (p->mismatch > 0 || p->gap > 0)) ? 2u : ctx->mode;
+    if (b->eff_mode == 0) {
+        // mode 0's 256-step direction tiles leave the least LDS for the staged alignment: batches with pairs too long for
+        // it run as mode 1 (or 2) -- the results are the same
+        uint32_t max_n = 0, max_m = 0;
+        for (const auto &d : b->ref_desc) max_n = std::max(max_n, d.len);
+        for (const auto &d : b->read_desc) max_m = std::max(max_m, d.len);
+        if (traceback_lds_bytes(0, path_bound(max_n, max_m, *p), max_m) > 160ull * 1024)
+            b->eff_mode = (p->mismatch > 0 || p->gap > 0) ? 2u : 1u;
+    }
     if (b->work_mode != (int)b->eff_mode) {
         b->work.clear();
         b->work.reserve(n_pairs);
