@@ -1223,8 +1223,10 @@ __device__ __forceinline__ uint32_t winmax_detect(const TraceArgs &A, const Pair
     const uint32_t nq0 = gc[0] + 1u < n_waves ? gc[0] + 1u : n_waves;             // windows of the span that ends with window gc[0]
     const uint32_t wlo0 = (gc[0] + 1u - nq0) * SWMI_CK_BLOCKS;
     if (wave == 0) {
+        if (n_waves == 1u)                                   // nobody else to do it
+            for (uint32_t w = lane; w < (m + 3u) / 4u; w += WAVE) walker_lds[A.lds_words + w] = readw[w];
         const uint32_t cnt = detect_cells<R, false>(A, pd, po, lane, pre ? tiles + (nq0 - 1u) * SWMI_CK_BLOCKS * R * WAVE : tiles);
-        publish(cnt, (pre && cnt == 1u) ? 1u : 0u);
+        publish(cnt, (pre && cnt == 1u && n_waves > 1u) ? 1u : 0u);
     } else {
         // the read's codes for the walkers: wave w fills walker w's copy, the last wave also walker 0's
         if (wave < SWMI_TB_SLOTS)
@@ -1286,9 +1288,10 @@ sw_traceback_winmax_kernel(const TraceArgs A) {
         }
         __syncthreads();
         const uint32_t c = shared[0];
-        if (c > ccap || wave >= c || wave >= SWMI_TB_SLOTS) return;
+        uint32_t nwr = c < SWMI_TB_SLOTS ? c : SWMI_TB_SLOTS;
+        if (nwr > n_waves) nwr = n_waves;
+        if (c > ccap || wave >= nwr) return;
         po.n_cells = c;
-        const uint32_t nwr = c < SWMI_TB_SLOTS ? c : SWMI_TB_SLOTS;
         uint32_t *lds = walker_lds0 + wave * per_walker;
         uint32_t *tile = tiles + wave * WIN_WORDS;
         if (R == 1)      traceback_pair<1, 1, false>(A, pd, po, lane, wave, nwr, lds, tile, nullptr, 1u);
@@ -1306,7 +1309,8 @@ sw_traceback_winmax_kernel(const TraceArgs A) {
     if (shared[3] != 1u) pre_wlo = 0xFFFFFFFFu;                        // no staged first spans
     if (cnt > ccap || cnt == 0u) return;
     po.n_cells = cnt;
-    const uint32_t nw = cnt < SWMI_TB_SLOTS ? cnt : SWMI_TB_SLOTS;     // walkers = teams
+    uint32_t nw = cnt < SWMI_TB_SLOTS ? cnt : SWMI_TB_SLOTS;           // walkers = teams
+    if (nw > n_waves) nw = n_waves;                                    // (a one-wave workgroup walks its alignments one after the other)
     const uint32_t ts = n_waves / nw;                                  // waves (= windows per round) per team
     if (ts == 1u) {
         // no helpers to share the re-sweeps with: the walkers run independently, one window at a time
@@ -1369,11 +1373,15 @@ extern "C" hipError_t swmi_launch_traceback(const TraceArgs *a, hipStream_t st) 
     const dim3 block(WAVE * FILL_WAVES);
     if (a->mode == 1) {
         // 8 waves per pair (bigger teams, shorter critical path) while every workgroup of the launch can be resident
-        // at once (4 waves per SIMD at this kernel's register count), else 4
+        // at once (4 waves per SIMD at this kernel's register count), else 4.  Big batches are throughput-bound: there a
+        // helper wave that mostly waits only takes a slot another pair's walker could use, so every pair gets ONE wave
+        // (it lists the cells, then walks the alignments one after the other).
         static int forced = getenv("SWMI_TB_WAVES") ? atoi(getenv("SWMI_TB_WAVES")) : 0;
-        const uint32_t n_waves = forced ? (uint32_t)forced : (a->n_pairs <= 512u ? SWMI_TB_WAVES : 4u);
+        static int big = getenv("SWMI_TB_BIG") ? atoi(getenv("SWMI_TB_BIG")) : 10000;   // measured crossover: between 8 k and 16 k pairs
+        const uint32_t n_waves = forced ? (uint32_t)forced : (a->n_pairs <= 512u ? SWMI_TB_WAVES : a->n_pairs <= (uint32_t)big ? 4u : 1u);
+        const size_t n_walkers = n_waves < SWMI_TB_SLOTS ? n_waves : SWMI_TB_SLOTS;
         const size_t words = 32 + (size_t)n_waves * SWMI_CK_BLOCKS * SWMI_RMAX * WAVE +
-                             (size_t)SWMI_TB_SLOTS * ((size_t)a->lds_words + a->lds_read_words + SWMI_TB_REFWIN_WORDS);
+                             n_walkers * ((size_t)a->lds_words + a->lds_read_words + SWMI_TB_REFWIN_WORDS);
         hipLaunchKernelGGL(sw_traceback_winmax_kernel, dim3(a->n_pairs), dim3(WAVE * n_waves), words * sizeof(uint32_t), st, *a);
     } else {
         const dim3 grid((a->n_pairs + FILL_WAVES - 1) / FILL_WAVES, SWMI_TB_SLOTS);
