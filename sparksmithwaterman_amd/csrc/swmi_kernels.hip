@@ -1223,10 +1223,12 @@ __device__ __forceinline__ uint32_t winmax_detect(const TraceArgs &A, const Pair
     const uint32_t nq0 = gc[0] + 1u < n_waves ? gc[0] + 1u : n_waves;             // windows of the span that ends with window gc[0]
     const uint32_t wlo0 = (gc[0] + 1u - nq0) * SWMI_CK_BLOCKS;
     if (wave == 0) {
-        if (n_waves == 1u)                                   // nobody else to do it
+        if (n_waves == 1u) {                                 // nobody else to do it
             for (uint32_t w = lane; w < (m + 3u) / 4u; w += WAVE) walker_lds[A.lds_words + w] = readw[w];
+            if (pre) stage_ref(walker_lds + A.lds_words + A.lds_read_words, wlo0, nq0);
+        }
         const uint32_t cnt = detect_cells<R, false>(A, pd, po, lane, pre ? tiles + (nq0 - 1u) * SWMI_CK_BLOCKS * R * WAVE : tiles);
-        publish(cnt, (pre && cnt == 1u && n_waves > 1u) ? 1u : 0u);
+        publish(cnt, (pre && cnt == 1u) ? 1u : 0u);       // (the candidate's window doubles as the first window of the walk)
     } else {
         // the read's codes for the walkers: wave w fills walker w's copy, the last wave also walker 0's
         if (wave < SWMI_TB_SLOTS)
