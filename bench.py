@@ -64,6 +64,13 @@ def main():
         sys.exit(2)
     else:
         torch.cuda.set_device(0)
+    # rehearsal of the multi-GPU step loop on ONE GPU: a one-rank nccl (RCCL) group with the exchange forced on, so that
+    # the helper thread issues real RCCL collectives next to the library's kernels (SWMI_BENCH_REHEARSE_RCCL=1)
+    rehearse_rccl = world == 1 and os.environ.get("SWMI_BENCH_REHEARSE_RCCL") == "1"
+    if rehearse_rccl:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     dev = torch.device("cpu") if (one_gpu and world > 1) else torch.device("cuda", local_rank)
 
     # ---- synthetic inputs: shard `rank` of a world*n_refs reference set, the read of shard 0 --------------
@@ -89,8 +96,8 @@ def main():
     gids = np.arange(id0, id0 + len(refs), dtype=np.int64)
 
     reducer = None
-    if world > 1:
-        reducer = swd.MaxReducer("cpu" if one_gpu else dev)    # buffers allocated once; one RCCL all-gather per step
+    if world > 1 or rehearse_rccl:
+        reducer = swd.MaxReducer("cpu" if one_gpu else dev, always_exchange=rehearse_rccl)    # buffers allocated once; one RCCL all-gather per step
 
     # The path's one exchange step (max total + its references) runs on a helper thread, one step behind, the way a
     # driver streaming shards would: batch.run() releases the GIL while it waits for the GPU, so the collective's
@@ -117,6 +124,9 @@ def main():
 
     worker = None
     if reducer is not None:
+        # the step loop wants the GIL back the moment batch.run() returns: a short switch interval makes the helper thread
+        # hand it over within microseconds instead of CPython's default 5 ms
+        sys.setswitchinterval(float(os.environ.get("SWMI_BENCH_SWITCH_INTERVAL", "1e-5")))
         worker = threading.Thread(target=reduce_worker, daemon=True)
         worker.start()
 
@@ -217,6 +227,7 @@ def main():
     ctx.close()
     if world > 1:
         dist.barrier()
+    if world > 1 or rehearse_rccl:
         dist.destroy_process_group()
 
 
