@@ -133,7 +133,7 @@ def main():
     def step():
         batch.run(params)
         if worker is not None:
-            work.put(batch.ref_totals().copy())
+            work.put(batch.ref_totals())              # (a fresh array per call)
 
     def drain():
         if worker is not None:
