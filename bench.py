@@ -99,49 +99,35 @@ def main():
     if world > 1 or rehearse_rccl:
         reducer = swd.MaxReducer("cpu" if one_gpu else dev, always_exchange=rehearse_rccl)    # buffers allocated once; one RCCL all-gather per step
 
-    # The path's one exchange step (max total + its references) runs on a helper thread, one step behind, the way a
-    # driver streaming shards would: batch.run() releases the GIL while it waits for the GPU, so the collective's
-    # host-side cost (~45 us of torch/RCCL calls) and its latency hide behind the next shard's kernels.  Every
-    # exchange of the timed steps has completed before the timed region ends (drain()).
-    import queue
-    import threading
-    work = queue.Queue()
-    results = []
-
-    def reduce_worker():
-        if dev.type == "cuda":
-            torch.cuda.set_device(dev)
-        while True:
-            item = work.get()
-            if item is None:
-                work.task_done()
-                return
-            try:
-                results.append(reducer(item, gids))
-            except BaseException as e:          # surfaced by drain()
-                results.append(e)
-            work.task_done()
-
-    worker = None
-    if reducer is not None:
-        # the step loop wants the GIL back the moment batch.run() returns: a short switch interval makes the helper thread
-        # hand it over within microseconds instead of CPython's default 5 ms
-        sys.setswitchinterval(float(os.environ.get("SWMI_BENCH_SWITCH_INTERVAL", "1e-5")))
-        worker = threading.Thread(target=reduce_worker, daemon=True)
-        worker.start()
+    # The path's one exchange step (max total + its references) is done for shard k-1 while the GPU works on shard k,
+    # the way a driver streaming shards would: the run is started on the library's own host thread
+    # (swmi_batch_run_async), this thread submits the exchange of the previous shard's totals and collects the one
+    # before, then waits for the run.  Every exchange of the timed steps has completed before the timed region ends.
+    pending = []               # tickets of submitted, not yet collected exchanges
+    prev_totals = [None]
+    last_result = [None]
 
     def step():
-        batch.run(params)
-        if worker is not None:
-            work.put(batch.ref_totals())              # (a fresh array per call)
+        if reducer is None:
+            batch.run(params)
+            return
+        batch.run_async(params)
+        if prev_totals[0] is not None:
+            pending.append(reducer.submit(prev_totals[0], gids))
+            if len(pending) > 1:
+                last_result[0] = reducer.collect(pending.pop(0))
+        batch.wait()
+        prev_totals[0] = batch.ref_totals()
 
     def drain():
-        if worker is not None:
-            work.join()
-            for r in results:
-                if isinstance(r, BaseException):
-                    raise r
-        return results[-1] if results else None
+        if reducer is None:
+            return None
+        if prev_totals[0] is not None:
+            pending.append(reducer.submit(prev_totals[0], gids))
+            prev_totals[0] = None
+        while pending:
+            last_result[0] = reducer.collect(pending.pop(0))
+        return last_result[0]
 
     def sync():
         if world > 1:
@@ -161,9 +147,6 @@ def main():
         fill_ms += t.fill_ms; tb_ms += t.traceback_ms; d2h_ms += t.d2h_ms; launches += t.fill_launches
     last = drain()
     sync()
-    if worker is not None:
-        work.put(None)
-        worker.join()
     elapsed = time.perf_counter() - t0
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:

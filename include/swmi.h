@@ -101,6 +101,12 @@ int  swmi_batch_upload(swmi_ctx *ctx,
  * the compact result records device->host.  Synchronous on return. */
 int  swmi_batch_run(swmi_ctx *ctx, swmi_batch *b, const swmi_params *p);
 void swmi_batch_free(swmi_ctx *ctx, swmi_batch *b);
+/* The same run on the context's own host thread: swmi_batch_run_async returns at once, swmi_batch_wait blocks until
+ * the run has finished and returns its status (one run in flight per context; results and accessors as after
+ * swmi_batch_run, to be used after the wait).  What a Spark task uses to prepare its next partition -- or bench.py's
+ * rank to do the previous shard's reduce -- while the GPU works. */
+int  swmi_batch_run_async(swmi_ctx *ctx, swmi_batch *b, const swmi_params *p);
+int  swmi_batch_wait(swmi_ctx *ctx);
 
 /* Stage timings of the last swmi_batch_run with option "profiling" = 1 (ms, HIP events
  * on the context's stream): fill kernel, traceback kernel, D2H; launches = number of

@@ -45,6 +45,8 @@ SYMBOLS = [
     ("swmi_set_option", C.c_int, [_P, C.c_char_p, C.c_int64]),
     ("swmi_batch_upload", C.c_int, [_P, C.c_char_p, _u64p, C.c_uint32, C.c_char_p, _u64p, C.c_uint32, C.POINTER(_P)]),
     ("swmi_batch_run", C.c_int, [_P, _P, C.POINTER(Params)]),
+    ("swmi_batch_run_async", C.c_int, [_P, _P, C.POINTER(Params)]),
+    ("swmi_batch_wait", C.c_int, [_P]),
     ("swmi_batch_free", None, [_P, _P]),
     ("swmi_batch_timing", C.c_int, [_P, C.POINTER(Timing)]),
     ("swmi_batch_n_pairs", C.c_uint64, [_P]),

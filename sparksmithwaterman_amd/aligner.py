@@ -68,6 +68,18 @@ class Batch:
         check(self._lib.swmi_batch_run(self._ctx._h, self._h, C.byref(p)))
         return self
 
+    def run_async(self, params=None):
+        """Starts the same run on the context's own host thread and returns at once; wait() completes it."""
+        p = params if params is not None else make_params()
+        self._async_params = p                     # (copied by the library before the call returns; kept for clarity)
+        check(self._lib.swmi_batch_run_async(self._ctx._h, self._h, C.byref(p)))
+        return self
+
+    def wait(self):
+        """Blocks until the run started by run_async() has finished; raises what it raised."""
+        check(self._lib.swmi_batch_wait(self._ctx._h))
+        return self
+
     def timing(self):
         t = Timing()
         check(self._lib.swmi_batch_timing(self._h, C.byref(t)))

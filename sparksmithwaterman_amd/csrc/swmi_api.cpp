@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -18,6 +19,7 @@
 #include <mutex>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/swmi.h"
@@ -103,6 +105,13 @@ struct swmi_ctx {
     uint64_t arena_copy_wpp = 48;           // arena words per pair fetched with the first D2H (tracks the last run)
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     PinnedBuf h_err;                        // one host-mapped word the kernels raise on an internal failure (strip pipeline timeout)
+    // swmi_batch_run_async: one run in flight on the context's own host thread
+    std::thread worker;
+    std::atomic<int> job_state{0};          // 0 idle, 1 submitted, 2 finished, 3 quit
+    swmi_batch *job_batch = nullptr;
+    swmi_params job_params{};
+    int job_rc = 0;
+    std::string job_err;
 };
 
 // one alignment as parsed from the arena
@@ -237,6 +246,11 @@ extern "C" int swmi_create(int device, swmi_ctx **out) {
 extern "C" void swmi_destroy(swmi_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    if (ctx->worker.joinable()) {
+        while (ctx->job_state.load(std::memory_order_acquire) == 1) std::this_thread::yield();   // a run still in flight
+        ctx->job_state.store(3, std::memory_order_release);
+        ctx->worker.join();
+    }
     for (auto &ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     ctx->h_err.release();
@@ -944,6 +958,52 @@ extern "C" int swmi_batch_run(swmi_ctx *ctx, swmi_batch *b, const swmi_params *p
     if (host_dbg)
         fprintf(stderr, "[swmi host] setup %.1f us, chunks (launch+wait+parse) %.1f us [enqueue %.1f, wait %.1f, copy-out %.1f], grouping %.1f us\n",
                 us(h0, h1), us(h1, h2), rs.enqueue_us, rs.wait_us, rs.copyout_us, us(h2, now()));
+    return SWMI_OK;
+}
+
+// ---- asynchronous run: the same swmi_batch_run on the context's own host thread -------------------------------
+// The caller gets its thread back while the GPU works (a Spark task can prepare its next partition, bench.py's rank
+// can do the previous step's reduce).  The helper thread spins briefly between jobs, so back-to-back runs start
+// without a wake-up latency, and sleeps when the context stays idle.
+static void swmi_worker_loop(swmi_ctx *ctx) {
+    for (;;) {
+        int st, idle = 0;
+        while ((st = ctx->job_state.load(std::memory_order_acquire)) != 1) {
+            if (st == 3) return;
+            if (++idle < 20000) { __builtin_ia32_pause(); }
+            else std::this_thread::sleep_for(std::chrono::microseconds(50));
+        }
+        const int rc = swmi_batch_run(ctx, ctx->job_batch, &ctx->job_params);
+        ctx->job_rc = rc;
+        ctx->job_err = rc ? swmi_last_error() : "";
+        ctx->job_state.store(2, std::memory_order_release);
+    }
+}
+
+extern "C" int swmi_batch_run_async(swmi_ctx *ctx, swmi_batch *b, const swmi_params *p) {
+    if (!ctx || !b || !p) return fail(SWMI_ERR_INVALID, "null argument");
+    if (ctx->job_state.load(std::memory_order_acquire) != 0)
+        return fail(SWMI_ERR_INVALID, "a run is already in flight on this context: call swmi_batch_wait first");
+    if (!ctx->worker.joinable()) ctx->worker = std::thread(swmi_worker_loop, ctx);
+    ctx->job_batch = b;
+    ctx->job_params = *p;
+    ctx->job_state.store(1, std::memory_order_release);
+    return SWMI_OK;
+}
+
+extern "C" int swmi_batch_wait(swmi_ctx *ctx) {
+    if (!ctx) return fail(SWMI_ERR_INVALID, "null argument");
+    int st = ctx->job_state.load(std::memory_order_acquire);
+    if (st == 0) return fail(SWMI_ERR_INVALID, "no run in flight on this context");
+    int spins = 0;
+    while (st != 2) {
+        if (++spins < 200000) __builtin_ia32_pause(); else std::this_thread::yield();
+        st = ctx->job_state.load(std::memory_order_acquire);
+    }
+    const int rc = ctx->job_rc;
+    const std::string err = ctx->job_err;
+    ctx->job_state.store(0, std::memory_order_release);
+    if (rc) return fail(rc, "%s", err.c_str());
     return SWMI_OK;
 }
 

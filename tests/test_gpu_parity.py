@@ -304,3 +304,20 @@ def test_fast_symbols_and_int4_score_bounds(ctx):
     for scores in ((5, -3, -4), (7, -8, -2), (1, -1, -1), (8, -3, -4), (5, -9, -4)):
         check_batch(ctx, refs, reads, scores=scores)
     check_batch(ctx, refs + seqs("ACGTNK", 2, (120,)), reads, tie=1)      # K is not a fast symbol
+
+
+def test_run_async_matches_run(ctx):
+    """swmi_batch_run_async + swmi_batch_wait: the same results as the blocking run, one run in flight per context."""
+    refs, reads = synth.config_1k(n_refs=24, ref_len=400, read_len=150)
+    b = ctx.upload(refs, reads)
+    b.run()
+    want = [(b.score(k), b.alignments(k)) for k in range(len(refs))]
+    for _ in range(3):
+        b.run_async()
+        with pytest.raises(sw.SwmiError):
+            b.run_async()                      # a second run while one is in flight is refused ...
+        b.wait()                               # ... and does not disturb the first
+        assert [(b.score(k), b.alignments(k)) for k in range(len(refs))] == want
+    with pytest.raises(sw.SwmiError):
+        b.wait()                               # nothing in flight
+    b.free()
