@@ -1,17 +1,22 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the Smith-Waterman hot path on N MI355X (contract in the task brief).
 
-A "step" is one pass of the hot path over one batch: fill + 2-bit direction field + tied-maximum lists +
-device traceback for every (reference, read) pair, compact result records device->host, and (N > 1) the
-max/top-K reduce over RCCL.  Inputs are resident in HBM before the timed region starts.
+A "step" is one pass of the hot path over one batch: score sweep + tied-maximum lists + device traceback for every
+(reference, read) pair, compact result records written to host memory, and (N > 1) the max/top-K reduce over RCCL.
+Inputs are resident in HBM before the timed region starts.
 
 N = 1 workload = BASELINE.json configs[1]: one 150 bp read x 1,000 synthetic 2 kbp references (3.0e8 cells,
 SplitMix64 seed 1).  N > 1: every rank holds its own 1,000-reference shard (weak scaling, references sharded
 as the reference's `parallelize(refs)` does); value = cells of ALL ranks / max-over-ranks time.
+
+`python bench.py --gpus N` (N > 1) without WORLD_SIZE in the environment starts the N rank processes itself (fresh
+children of a parent that never touches the GPU); under `torch.distributed.run` it is one of the ranks.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -20,13 +25,20 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
+WORKLOAD_OF_MODE = {
+    1: "score-only sweep (lane-state checkpoints + one maximum per 32-step window) + traceback by window re-sweep "
+       "(tied maxima listed, alignments walked) + result records written to host memory",
+    2: "score-only sweep (checkpoints, tied maxima tracked by events) + traceback by window re-sweep + result records",
+    0: "sweep writing the 2-bit direction field to HBM + tied maxima + traceback over the field + result records",
+}
+
 
 def alg_bytes(m, n):
     """packed ref + packed read + 2-bit direction field + traceback re-read + record."""
     return -(-n // 4) + -(-m // 4) + -(-(m * n) // 4) + -(-(m + n) // 4) + 16
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -37,8 +49,68 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--d2h-copy", action="store_true", help="fetch results with a D2H copy instead of zero-copy writes to pinned memory")
     ap.add_argument("--mode", type=int, default=None, help="kernel pipeline (include/swmi.h): 1 default, 2 event-tracked maxima, 0 HBM direction field")
-    args = ap.parse_args()
+    return ap.parse_args()
 
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(args):
+    """--gpus N with no rendezvous in the environment: this process becomes a launcher.  It makes NO GPU call (it does
+    not even import torch): the ranks are fresh children, never a re-exec of a process that touched the GPU.
+    Rank 0 prints the JSON line on the inherited stdout; a failed rank ends the others and the exit code is non-zero."""
+    n = args.gpus
+    env = dict(os.environ)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    env.setdefault("MASTER_PORT", str(free_port()))
+    env["WORLD_SIZE"] = str(n)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = []
+    for r in range(n):
+        e = dict(env)
+        e["RANK"] = str(r)
+        e["LOCAL_RANK"] = str(r)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e))
+    rc = 0
+    alive = list(procs)
+    while alive:
+        for p in list(alive):
+            code = p.poll()
+            if code is None:
+                continue
+            alive.remove(p)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                for q in alive:          # the exact processes this launcher started, nothing else
+                    q.terminate()
+        time.sleep(0.05)
+    sys.exit(rc)
+
+
+def effective_cores():
+    """Host cores this process may really use: the affinity mask, capped by the cgroup CPU quota (a GPU box hands a
+    one-GPU job a 16-core share of a 256-thread host)."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, -(-int(quota) // int(period))))
+    except Exception:
+        pass
+    return cores
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args)          # never returns
+
+    import numpy as np
     import torch
     import torch.distributed as dist
     import sparksmithwaterman_amd as sw
@@ -48,8 +120,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # rehearsal on a one-GPU box: SWMI_BENCH_ONE_GPU=1 puts every rank on GPU 0 and uses gloo for the reduce
-    one_gpu = os.environ.get("SWMI_BENCH_ONE_GPU") == "1"
+    # rehearsal on a box with fewer GPUs than ranks (torch.cuda.device_count() does not initialise the GPU): every rank
+    # on GPU 0 and gloo for the reduce.  SWMI_BENCH_ONE_GPU=1 forces it.
+    n_dev = torch.cuda.device_count()
+    one_gpu = world > 1 and (os.environ.get("SWMI_BENCH_ONE_GPU") == "1" or n_dev < world)
     if one_gpu:
         local_rank = 0
     if world > 1:
@@ -59,9 +133,6 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    elif args.gpus > 1:
-        print("bench.py --gpus %d must be launched through torch.distributed.run" % args.gpus, file=sys.stderr)
-        sys.exit(2)
     else:
         torch.cuda.set_device(0)
     # rehearsal of the multi-GPU step loop on ONE GPU: a one-rank nccl (RCCL) group with the exchange forced on, so that
@@ -87,12 +158,12 @@ def main():
         ctx.set_option("mode", args.mode)
     if args.d2h_copy:
         ctx.set_option("zero_copy", 0)
-    mode = 1 if args.mode is None else args.mode
-    kernel_name = {0: "sw_fill_kernel", 1: "sw_sweep_winmax_kernel", 2: "sw_fill_score_kernel"}[mode]
     batch = ctx.upload(refs, reads)          # H2D happens here, outside the timed region
     params = sw.make_params()
+    batch.run(params)
+    mode = batch.pipeline_mode()             # the pipeline the library chose for this batch (or the one forced above)
+    kernel_name = {0: "sw_fill_kernel", 1: "sw_sweep_winmax_kernel", 2: "sw_fill_score_kernel"}[mode]
 
-    import numpy as np
     gids = np.arange(id0, id0 + len(refs), dtype=np.int64)
 
     reducer = None
@@ -153,7 +224,27 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
 
-    # ---- parity spot check on the bench inputs (outside the timed region) ---------------------------------
+    # ---- outside the timed region -----------------------------------------------------------------------
+    # (a) the reduce on its own: blocking exchanges of this shard's totals
+    reduce_ms = None
+    if reducer is not None:
+        tot = batch.ref_totals()
+        for _ in range(3):
+            reducer(tot, gids)
+        sync()
+        r0 = time.perf_counter()
+        for _ in range(20):
+            reducer(tot, gids)
+        reduce_ms = (time.perf_counter() - r0) / 20 * 1e3
+    # (b) a second, labelled figure: the step INCLUDING what OptAlignments hands back -- record index + every string
+    mat_steps = max(3, min(args.steps, 20))
+    sync()
+    m0 = time.perf_counter()
+    for _ in range(mat_steps):
+        batch.run(params)
+        n_aln_all, n_chars = batch.materialise_all()
+    ms_mat = (time.perf_counter() - m0) / mat_steps * 1e3
+    gpu_scores, gpu_naln = batch.pair_results()
     winner = int(np.argmax(batch.ref_totals()))
 
     if rank == 0:
@@ -163,22 +254,25 @@ def main():
         achieved = bytes_rank / fill_avg_s / 1e9 if fill_avg_s > 0 else 0.0
         traffic = None
         tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        prof = {}
         if os.path.exists(tf):
             try:
-                traffic = json.load(open(tf)).get("fill_kernel_hbm_bytes_per_launch")
+                prof = json.load(open(tf))
+                traffic = prof.get("fill_kernel_hbm_bytes_per_launch")
             except Exception:
-                traffic = None
+                prof, traffic = {}, None
         # supplementary: the bound that actually holds for this integer recurrence is instruction issue (DESIGN.md
         # 4.1).  Instructions per pair come from the committed PMC run and are only valid for the default workload.
         issue = None
         try:
-            ipp = json.load(open(tf)).get("sweep_insts_per_pair_headline") if os.path.exists(tf) else None
-            if ipp and (m, args.ref_len, len(refs), len(reads)) == (150, 2000, 1000, 1) and args.mode in (None, 1) and fill_avg_s > 0:
+            ipp = prof.get("sweep_insts_per_pair_headline")
+            if ipp and (m, args.ref_len, len(refs), len(reads)) == (150, 2000, 1000, 1) and mode == 1 and fill_avg_s > 0:
                 insts = (ipp["valu"] + ipp["salu"]) * len(refs) * len(reads)
-                peak = 1024 * 2.4e9 / 4.45           # SIMDs x max clock / cycles per instruction of ONE wave per SIMD (tools/ubench.hip)
+                nominal = 1024 * 2.4e9 / 2.0         # SIMDs x max clock / 2 cycles per wave64 VALU (the guide's nominal rate)
+                lone = 1024 * 2.4e9 / 4.0            # ... / 4 cycles: what ONE wave per SIMD can issue (guide, 'one wave alone: 4')
                 issue = {"insts_per_launch": insts, "achieved_ginst_s": round(insts / fill_avg_s / 1e9, 1),
-                         "peak_ginst_s_one_wave_per_simd": round(peak / 1e9, 1),
-                         "frac": round(insts / fill_avg_s / peak, 4)}
+                         "frac_of_nominal_2cyc": round(insts / fill_avg_s / nominal, 4),
+                         "frac_of_one_wave_per_simd_4cyc": round(insts / fill_avg_s / lone, 4)}
         except Exception:
             issue = None
         out = {
@@ -187,12 +281,16 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "alignments_per_s": round(len(refs) * len(reads) * world * args.steps / elapsed, 1),
-            "config": {"workload": "configs[1]: 1 read x %d bp vs %d refs x %d bp per GPU, scores 5/-3/-4, "
-                                   "fill+direction field+tied maxima+traceback+result D2H"
-                                   % (m, len(refs), args.ref_len),
+            "ms_per_step_materialised": round(ms_mat, 4),
+            "materialised": {"what": "run + record index + both strings of every alignment (swmi_batch_materialise_all), "
+                                     "rank 0, outside the timed region", "steps": mat_steps,
+                             "alignments": int(n_aln_all), "chars": int(n_chars),
+                             "gcups": round(cells_rank / (ms_mat * 1e-3) / 1e9, 3)},
+            "config": {"workload": "configs[1]: 1 read x %d bp vs %d refs x %d bp per GPU, scores 5/-3/-4, mode %d: %s"
+                                   % (m, len(refs), args.ref_len, mode, WORKLOAD_OF_MODE[mode]),
                        "pairs_per_gpu": len(refs) * len(reads), "cells_per_step_per_gpu": cells_rank,
                        "parallelism": "references sharded over %d rank(s); max/top-K reduce %s"
-                                      % (world, "over RCCL" if world > 1 else "local")},
+                                      % (world, ("over gloo (one-GPU rehearsal)" if one_gpu else "over RCCL") if world > 1 else "local")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "kernel": kernel_name, "kernel_avg_ms": round(fill_avg_s * 1e3, 4),
@@ -201,11 +299,18 @@ def main():
                          "traceback_avg_ms": round(tb_ms / args.steps, 4), "d2h_avg_ms": round(d2h_ms / args.steps, 4)},
             "check": {"winner_ref": winner, "winner_total": batch.ref_total(winner)},
         }
+        if reduce_ms is not None:
+            out["reduce_ms"] = round(reduce_ms, 4)
+            out["reduce"] = {"what": "one blocking max-with-ties exchange (all_gather of {local max, winners}), measured "
+                                     "on its own outside the timed region; inside it the exchange overlaps the next shard",
+                             "result": [int(last[0]), [int(x) for x in last[1]][:8]] if last else None}
         if issue:
             out["roofline"]["issue"] = issue
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(refs, reads)
-        print(json.dumps(out))
+            base, chk = cpu_baseline(refs, reads, gpu_scores, gpu_naln)
+            out["cpu_baseline"] = base
+            out["check"].update(chk)
+        print(json.dumps(out), flush=True)
     batch.free()
     ctx.close()
     if world > 1:
@@ -214,23 +319,32 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(refs, reads):
-    """The oracle's full path (C restatement of the Java code, NOT the JVM) on all host cores, on a bounded
-    sample: the same 1k-reference batch repeated until ~12 s of wall time have been spent."""
+def cpu_baseline(refs, reads, gpu_scores, gpu_naln):
+    """The oracle's full path (C restatement of the Java code, NOT the JVM) on the host cores this job owns, on a
+    bounded sample: the same 1k-reference batch, `reps` passes (~12 s) by a thread pool that exists before the clock
+    starts.  The same pass yields every pair's score and alignment count, compared here with the GPU's."""
     from oracle import sw_oracle as orc
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    r = orc.bench(refs[:100], reads, nthreads=cores)            # calibration, 3e7 cells
+    cores = effective_cores()
+    r = orc.bench(refs[:max(4 * cores, 64)], reads, nthreads=cores)            # calibration
     rate = r["cells"] / max(r["seconds"], 1e-9)
-    n = int(min(len(refs), max(100, rate * 12.0 / (len(refs[0]) * len(reads[0])))))
-    reps = max(1, int(rate * 12.0 / (sum(len(x) for x in refs[:n]) * len(reads[0]))))
-    reps = min(reps, 40)
-    cells = secs = 0
-    for _ in range(reps):
-        r = orc.bench(refs[:n], reads, nthreads=cores)
-        cells += r["cells"]; secs += r["seconds"]
-    return {"value": round(cells / secs / 1e9, 4), "unit": "GCUPS", "cores": cores, "kind": "port",
-            "sample": "%d x the first %d pairs of the same batch (%.1f s); C restatement of "
-                      "SmithWaterman.OptAlignments, one pair per task, pthreads" % (reps, n, secs)}
+    per_pass = sum(len(x) for x in refs) * sum(len(q) for q in reads)
+    reps = int(max(1, min(200, rate * 12.0 / per_pass)))
+    while reps * len(refs) * len(reads) < 16 * cores:                          # >= 16 pairs per thread
+        reps += 1
+    r = orc.bench(refs, reads, nthreads=cores, reps=reps, per_pair=True)
+    mism = sum(1 for k in range(len(refs) * len(reads))
+               if int(gpu_scores[k]) != r["pair_score"][k] or int(gpu_naln[k]) != r["pair_naln"][k])
+    gc = r["cells"] / r["seconds"] / 1e9
+    base = {"value": round(gc, 4), "unit": "GCUPS", "cores": cores, "kind": "port",
+            "mcups_per_core": round(gc * 1e3 / cores, 1),
+            "sample": "%d passes over the same %d pairs (%.1f s); C restatement of SmithWaterman.OptAlignments "
+                      "(full int + char matrices, all tied maxima, stack traceback), one pair per task, persistent "
+                      "pool of %d pthreads" % (reps, len(refs) * len(reads), r["seconds"], cores)}
+    chk = {"pairs_compared": len(refs) * len(reads), "mismatches": mism,
+           "compared": "score and number of alignments of every pair, GPU vs oracle, same run",
+           "sum_score": [int(sum(int(x) for x in gpu_scores)), r["sum_score"]],
+           "sum_alignments": [int(sum(int(x) for x in gpu_naln)), r["sum_aln"]]}
+    return base, chk
 
 
 if __name__ == "__main__":

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define SWMI_ABI_VERSION 1
+#define SWMI_ABI_VERSION 2
 
 typedef enum swmi_status {
     SWMI_OK               =  0,
@@ -88,7 +88,12 @@ void        swmi_default_params(swmi_params *p);
  *   2            as 1, but tied maxima are tracked during the sweep (per-step test + rare handler).
  *   0            the sweep writes the whole 2-bit direction field to HBM and the traceback reads it
  *                (cheaper when most pairs have many tied maxima).  Batches with pairs longer than about
- *                16 k bases (m + n) run as mode 1/2: mode 0's traceback tiles leave too little LDS for them. */
+ *                16 k bases (m + n) run as mode 1/2: mode 0's traceback tiles leave too little LDS for them.
+ *  -1            automatic (the default): mode 1, unless a sample of the batch's pairs (aligned once, on the first
+ *                run of the batch) shows many tied maxima per pair -- periodic references -- where mode 0 is faster.
+ * Further knobs: spin_us (how long a run polls its stream before it blocks, default 2000); col_chunks (0 automatic,
+ * 1 never, N > 1 force up to N column chunks per pair: a launch of few pairs with long references is swept by several
+ * wavefronts per pair); debug_strip_spins / debug_reverse_strips (tests of the strip pipeline's give-up path). */
 int         swmi_set_option(swmi_ctx *ctx, const char *name, int64_t value);
 
 /* ---- staged path: upload once, run many times (what bench.py times) ------------- */
@@ -116,8 +121,12 @@ typedef struct swmi_timing {
     uint32_t fill_launches, rerun_pairs;
     uint64_t cells;             /* sum of m*n over the pairs of the run            */
     uint64_t dir_bytes;         /* direction-field bytes written                   */
+    uint32_t strip_fallbacks;   /* launches repeated with the one-wavefront sweep after the strip pipeline gave up */
+    uint32_t col_chunks;        /* column-chunk wavefronts the sweep of the run was split into (0: one per pair)    */
 } swmi_timing;
 int  swmi_batch_timing(const swmi_batch *b, swmi_timing *t);
+/* The kernel pipeline (0, 1 or 2, see swmi_set_option "mode") the last run of the batch used. */
+int  swmi_batch_mode(const swmi_batch *b, int *mode);
 
 /* ---- results of the last run (host memory owned by the batch) ------------------- */
 #define SWMI_PAIR_DEGENERATE 0x1u   /* max score 0: every one of the m*n cells is a "max cell" and
@@ -125,12 +134,19 @@ int  swmi_batch_timing(const swmi_batch *b, swmi_timing *t);
 uint64_t swmi_batch_n_pairs(const swmi_batch *b);
 int      swmi_pair_score(const swmi_batch *b, uint64_t pair, int32_t *score);
 int      swmi_pair_n_alignments(const swmi_batch *b, uint64_t pair, uint64_t *n, uint32_t *flags);
+/* all pairs at once: scores[n] and/or n_alignments[n] (either may be NULL), n = swmi_batch_n_pairs */
+int      swmi_batch_pair_results(const swmi_batch *b, int32_t *scores, uint64_t *n_alignments, uint64_t n);
 /* k-th alignment of the pair in OptAlignments order.  *ref_aln / *read_aln point to
  * NUL-terminated strings owned by the batch (valid until the next run/free);
  * characters keep the caller's original case, gaps are '_' (SmithWaterman.java:356). */
 int      swmi_pair_alignment(swmi_batch *b, uint64_t pair, uint64_t k,
                              int32_t *begin, int32_t *end_i, int32_t *end_j,
                              const char **ref_aln, const char **read_aln, uint32_t *len);
+
+/* Builds the record index and both strings of EVERY alignment of the batch in one native call (what a caller that
+ * consumes all of OptAlignments' output pays); returns the number of alignments (degenerate pairs count m*n) and
+ * of characters built. */
+int      swmi_batch_materialise_all(swmi_batch *b, uint64_t *n_alignments, uint64_t *n_chars);
 
 /* ---- MapRef view: per reference, over all reads (Distribution.java:403-436) ------ */
 /* total = sum over reads of the pair scores (Java int, wrapping) (:424). */

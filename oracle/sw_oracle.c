@@ -362,26 +362,37 @@ typedef struct {
     const unsigned char *refs; const int64_t *ref_off; int64_t n_refs;
     const unsigned char *reads; const int64_t *read_off; int64_t n_reads;
     const int32_t *scores; const char *types; int tie_mode;
-    int64_t next; pthread_mutex_t mu;
+    int64_t reps;
+    int64_t next;                       /* task counter (atomic) */
+    pthread_mutex_t mu;
+    pthread_barrier_t start, stop;      /* the clock runs between the two: thread creation and joins are outside it */
     int64_t sum_score, sum_aln, cells;
+    int32_t *pair_score; int64_t *pair_naln;   /* optional per-pair outputs (pair = ref * n_reads + read) */
 } bench_job;
 
 static void *bench_worker(void *p) {
     bench_job *b = (bench_job *)p;
     int64_t ls = 0, la = 0, lc = 0;
     sw_oracle_scratch scr = { NULL, NULL, 0 };
+    const int64_t per_rep = b->n_refs * b->n_reads, total = per_rep * b->reps;
+    pthread_barrier_wait(&b->start);
     for (;;) {
-        pthread_mutex_lock(&b->mu);
-        int64_t t = b->next++;
-        pthread_mutex_unlock(&b->mu);
-        if (t >= b->n_refs * b->n_reads) break;
+        int64_t t = __atomic_fetch_add(&b->next, 1, __ATOMIC_RELAXED);
+        if (t >= total) break;
+        t %= per_rep;
         int64_t r = t / b->n_reads, q = t % b->n_reads;
         int64_t n = b->ref_off[r + 1] - b->ref_off[r], m = b->read_off[q + 1] - b->read_off[q];
         sw_oracle_result *res = align_impl(b->refs + b->ref_off[r], n,
                                            b->reads + b->read_off[q], m,
                                            b->scores, b->types, b->tie_mode, 0, &scr);
-        if (res) { ls += res->score; la += res->n_aln; lc += m * n; sw_oracle_free(res); }
+        if (res) {
+            ls += res->score; la += res->n_aln; lc += m * n;
+            if (b->pair_score) b->pair_score[t] = res->score;
+            if (b->pair_naln) b->pair_naln[t] = res->n_aln;
+            sw_oracle_free(res);
+        }
     }
+    pthread_barrier_wait(&b->stop);
     free(scr.H); free(scr.T);
     pthread_mutex_lock(&b->mu);
     b->sum_score += ls; b->sum_aln += la; b->cells += lc;
@@ -389,24 +400,35 @@ static void *bench_worker(void *p) {
     return NULL;
 }
 
+/* `reps` passes over the refs x reads task list by a pool of `nthreads` threads that exists before the clock starts
+ * (a persistent pool: starting 256 threads costs as much as aligning a few pairs).  The sums cover all passes. */
 double sw_oracle_bench(const unsigned char *refs, const int64_t *ref_off, int64_t n_refs,
                        const unsigned char *reads, const int64_t *read_off, int64_t n_reads,
                        const int32_t scores[3], const char types[4], int tie_mode,
-                       int nthreads, int64_t *sum_score, int64_t *sum_aln, int64_t *cells) {
+                       int nthreads, int reps, int64_t *sum_score, int64_t *sum_aln, int64_t *cells,
+                       int32_t *pair_score, int64_t *pair_naln) {
     bench_job b;
     memset(&b, 0, sizeof(b));
     b.refs = refs; b.ref_off = ref_off; b.n_refs = n_refs;
     b.reads = reads; b.read_off = read_off; b.n_reads = n_reads;
     b.scores = scores; b.types = types; b.tie_mode = tie_mode;
+    b.reps = reps < 1 ? 1 : reps;
+    b.pair_score = pair_score; b.pair_naln = pair_naln;
     pthread_mutex_init(&b.mu, NULL);
     if (nthreads < 1) nthreads = 1;
+    pthread_barrier_init(&b.start, NULL, (unsigned)nthreads + 1);
+    pthread_barrier_init(&b.stop, NULL, (unsigned)nthreads + 1);
     pthread_t *th = (pthread_t *)malloc((size_t)nthreads * sizeof(pthread_t));
     struct timespec t0, t1;
-    clock_gettime(CLOCK_MONOTONIC, &t0);
     for (int k = 0; k < nthreads; k++) pthread_create(&th[k], NULL, bench_worker, &b);
-    for (int k = 0; k < nthreads; k++) pthread_join(th[k], NULL);
+    pthread_barrier_wait(&b.start);
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    pthread_barrier_wait(&b.stop);
     clock_gettime(CLOCK_MONOTONIC, &t1);
+    for (int k = 0; k < nthreads; k++) pthread_join(th[k], NULL);
     free(th);
+    pthread_barrier_destroy(&b.start);
+    pthread_barrier_destroy(&b.stop);
     pthread_mutex_destroy(&b.mu);
     if (sum_score) *sum_score = b.sum_score;
     if (sum_aln) *sum_aln = b.sum_aln;

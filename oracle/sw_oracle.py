@@ -56,8 +56,9 @@ def lib():
         L.sw_oracle_bench.restype = C.c_double
         L.sw_oracle_bench.argtypes = [C.c_char_p, C.POINTER(C.c_int64), C.c_int64,
                                       C.c_char_p, C.POINTER(C.c_int64), C.c_int64,
-                                      C.POINTER(C.c_int32), C.c_char_p, C.c_int, C.c_int,
-                                      C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+                                      C.POINTER(C.c_int32), C.c_char_p, C.c_int, C.c_int, C.c_int,
+                                      C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                      C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
         _lib = L
     return _lib
 
@@ -133,13 +134,22 @@ def map_ref(ref, reads, align_scores=DEFAULT_SCORES, align_types=DEFAULT_TYPES, 
 
 
 def bench(refs, reads, align_scores=DEFAULT_SCORES, align_types=DEFAULT_TYPES,
-          tie_mode=TIE_SERIAL, nthreads=1):
-    """Times the full CPU path over refs x reads. Returns dict(seconds, cells, sum_score, sum_aln)."""
+          tie_mode=TIE_SERIAL, nthreads=1, reps=1, per_pair=False):
+    """Times the full CPU path over refs x reads, `reps` passes by a thread pool started before the clock.
+    Returns dict(seconds, cells (all passes), sum_score, sum_aln (one pass)); per_pair=True adds the lists
+    pair_score / pair_naln (pair = ref * n_reads + read)."""
     L = lib()
     rblob, roff = pack(refs)
     qblob, qoff = pack(reads)
     sc = (C.c_int32 * 3)(*align_scores)
     ss, sa, cc = C.c_int64(), C.c_int64(), C.c_int64()
+    npair = len(refs) * len(reads)
+    ps = (C.c_int32 * max(npair, 1))() if per_pair else None
+    pa = (C.c_int64 * max(npair, 1))() if per_pair else None
     sec = L.sw_oracle_bench(rblob, roff, len(refs), qblob, qoff, len(reads), sc, _b(align_types),
-                            tie_mode, nthreads, C.byref(ss), C.byref(sa), C.byref(cc))
-    return {"seconds": sec, "cells": cc.value, "sum_score": ss.value, "sum_aln": sa.value}
+                            tie_mode, nthreads, reps, C.byref(ss), C.byref(sa), C.byref(cc), ps, pa)
+    out = {"seconds": sec, "cells": cc.value, "sum_score": ss.value // reps, "sum_aln": sa.value // reps}
+    if per_pair:
+        out["pair_score"] = list(ps[:npair])
+        out["pair_naln"] = list(pa[:npair])
+    return out

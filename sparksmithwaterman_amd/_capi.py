@@ -28,7 +28,8 @@ class Params(C.Structure):
 class Timing(C.Structure):
     _fields_ = [("fill_ms", C.c_float), ("traceback_ms", C.c_float), ("d2h_ms", C.c_float),
                 ("total_ms", C.c_float), ("fill_launches", C.c_uint32), ("rerun_pairs", C.c_uint32),
-                ("cells", C.c_uint64), ("dir_bytes", C.c_uint64)]
+                ("cells", C.c_uint64), ("dir_bytes", C.c_uint64),
+                ("strip_fallbacks", C.c_uint32), ("col_chunks", C.c_uint32)]
 
 
 # every symbol include/swmi.h declares: (name, restype, argtypes)
@@ -49,12 +50,15 @@ SYMBOLS = [
     ("swmi_batch_wait", C.c_int, [_P]),
     ("swmi_batch_free", None, [_P, _P]),
     ("swmi_batch_timing", C.c_int, [_P, C.POINTER(Timing)]),
+    ("swmi_batch_mode", C.c_int, [_P, C.POINTER(C.c_int)]),
     ("swmi_batch_n_pairs", C.c_uint64, [_P]),
     ("swmi_pair_score", C.c_int, [_P, C.c_uint64, C.POINTER(C.c_int32)]),
     ("swmi_pair_n_alignments", C.c_int, [_P, C.c_uint64, _u64p, C.POINTER(C.c_uint32)]),
     ("swmi_pair_alignment", C.c_int, [_P, C.c_uint64, C.c_uint64, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                       C.POINTER(C.c_int32), C.POINTER(C.c_char_p), C.POINTER(C.c_char_p),
                                       C.POINTER(C.c_uint32)]),
+    ("swmi_batch_pair_results", C.c_int, [_P, C.POINTER(C.c_int32), _u64p, C.c_uint64]),
+    ("swmi_batch_materialise_all", C.c_int, [_P, _u64p, _u64p]),
     ("swmi_ref_total", C.c_int, [_P, C.c_uint32, C.POINTER(C.c_int32)]),
     ("swmi_ref_totals", C.c_int, [_P, C.POINTER(C.c_int32), C.c_uint32]),
     ("swmi_ref_n_match_sites", C.c_int, [_P, C.c_uint32, _u64p]),

@@ -85,6 +85,11 @@ class Batch:
         check(self._lib.swmi_batch_timing(self._h, C.byref(t)))
         return t
 
+    def pipeline_mode(self):
+        v = C.c_int()
+        check(self._lib.swmi_batch_mode(self._h, C.byref(v)))
+        return v.value
+
     # ---- per pair -------------------------------------------------------------------
     def score(self, pair):
         v = C.c_int32()
@@ -107,6 +112,22 @@ class Batch:
     def alignments(self, pair, with_cell=False):
         n, _ = self.n_alignments(pair)
         return [self.alignment(pair, k, with_cell) for k in range(n)]
+
+    def pair_results(self):
+        """(scores int32[n_pairs], n_alignments uint64[n_pairs]) as numpy arrays, one native call."""
+        import numpy as np
+        n = self.n_refs * self.n_reads
+        sc = np.empty(n, dtype=np.int32)
+        na = np.empty(n, dtype=np.uint64)
+        check(self._lib.swmi_batch_pair_results(self._h, sc.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                na.ctypes.data_as(C.POINTER(C.c_uint64)), n))
+        return sc, na
+
+    def materialise_all(self):
+        """Index the records and build every alignment string natively; returns (n_alignments, n_chars)."""
+        na, nc = C.c_uint64(), C.c_uint64()
+        check(self._lib.swmi_batch_materialise_all(self._h, C.byref(na), C.byref(nc)))
+        return na.value, nc.value
 
     # ---- MapRef view -----------------------------------------------------------------
     def ref_total(self, ref):

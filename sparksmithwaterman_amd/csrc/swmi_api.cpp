@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -27,6 +28,8 @@
 
 extern "C" hipError_t swmi_launch_fill(const FillArgs *a, hipStream_t st);
 extern "C" hipError_t swmi_launch_traceback(const TraceArgs *a, hipStream_t st);
+extern "C" hipError_t swmi_launch_encode(const uint8_t *raw, const uint64_t *raw_off, SeqDesc *desc, uint32_t *seqw,
+                                         const uint8_t *lut, uint32_t n_seq, hipStream_t st);
 
 // ------------------------------------------------------------------------------------------
 // errors
@@ -105,8 +108,17 @@ struct swmi_ctx {
     uint64_t arena_copy_wpp = 48;           // arena words per pair fetched with the first D2H (tracks the last run)
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     PinnedBuf h_err;                        // one host-mapped word the kernels raise on an internal failure (strip pipeline timeout)
+    DevBuf d_lut;                           // 256-byte canonical-code table of the encode kernel
+    int64_t spin_us = 2000;                 // how long a run polls its stream for completion before it blocks (a batch is sub-millisecond)
+    uint32_t dbg_strip_spins = 0;           // test knob: spin budget of the strip pipeline (0 = default)
+    uint32_t dbg_reverse_strips = 0;        // test knob: strip items dispatched consumer-first
+    int auto_mode = 1;                      // choose the pipeline per batch unless "mode" was set explicitly
+    uint32_t auto_ties_x100 = 300;          // automatic mode: mode 0 when a sampled pair has this many tied maxima (x 1/100) on average
+    uint32_t col_chunks = 0;                // test knob: force this many column chunks per pair (0 = automatic)
     // swmi_batch_run_async: one run in flight on the context's own host thread
     std::thread worker;
+    std::mutex job_mu;
+    std::condition_variable job_cv;
     std::atomic<int> job_state{0};          // 0 idle, 1 submitted, 2 finished, 3 quit
     swmi_batch *job_batch = nullptr;
     swmi_params job_params{};
@@ -147,12 +159,17 @@ struct swmi_batch {
     std::vector<uint64_t> ref_off, read_off;
     std::vector<SeqDesc> ref_desc, read_desc;
     // device
+    DevBuf d_raw, d_raw_off;                // the caller's bytes as uploaded (input of the encode kernel) and their offsets
     DevBuf d_seqw, d_refs, d_reads, d_pairs, d_dir, d_seam, d_result, d_cells, d_cells_off, d_cells_cap, d_dbg, d_dbg2;
     DevBuf d_strip_items, d_progress;       // mode 1: strip-per-wavefront sweep of long reads
+    DevBuf d_col_items;                     // mode 1: column chunks of single-strip pairs
+    bool acgt_known = false;                // ref_desc/read_desc[].acgt fetched back from the device (set there by the encode kernel)
     PinnedBuf h_result;
     // per run
     swmi_params params{};
     bool has_run = false;
+    int auto_choice = -1;                   // pipeline chosen by the sampled pre-pass (automatic mode), -1: not decided yet
+    swmi_params auto_params{};
     std::vector<Work> work;                 // schedule (pairs sorted by work), valid for work_mode
     int work_mode = -1;
     uint32_t eff_mode = 1;                  // pipeline of the current run
@@ -169,7 +186,9 @@ struct swmi_batch {
         int mode = -1;
         uint64_t dir_words = 0, seam_words = 0;
         uint32_t max_path = 0, max_read = 0;
-        size_t n_strip_items = 0;
+        size_t n_strip_items = 0, n_col_items = 0;
+        uint32_t col_chunks_opt = 0;
+        bool reverse_strips = false;
     } prep;
     std::vector<PairRes> pairs;             // by pair index
     // raw record streams of the last run (one per launch chunk), indexed lazily on the first alignment access
@@ -186,6 +205,8 @@ struct swmi_batch {
     std::vector<uint64_t> ref_degenerate;   // leading (0,"","") sites per ref
     swmi_timing timing{};
 };
+
+static const uint8_t *code_table();
 
 // ------------------------------------------------------------------------------------------
 // library / context
@@ -210,6 +231,14 @@ extern "C" void swmi_default_params(swmi_params *p) {
     p->types[0] = 'a'; p->types[1] = 'i'; p->types[2] = 'd'; p->types[3] = '-';   // Distribution.java:37
 }
 
+static void ctx_release(swmi_ctx *c) {
+    for (auto &ev : c->ev) if (ev) (void)hipEventDestroy(ev);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    c->h_err.release();
+    c->d_lut.release();
+    delete c;
+}
+
 extern "C" int swmi_create(int device, swmi_ctx **out) {
     if (!out) return fail(SWMI_ERR_INVALID, "out is null");
     *out = nullptr;
@@ -227,19 +256,21 @@ extern "C" int swmi_create(int device, swmi_ctx **out) {
                     device, prop.gcnArchName);
     e = hipSetDevice(device);
     if (e != hipSuccess) return fail(SWMI_ERR_NO_DEVICE, "hipSetDevice: %s", hipGetErrorString(e));
-    (void)hipSetDeviceFlags(hipDeviceScheduleSpin);      // a batch is sub-millisecond: spin on completion (ignored if the device is already active)
-    (void)hipGetLastError();
-    std::unique_ptr<swmi_ctx> c(new swmi_ctx);
+    // (no process-wide hipSetDeviceFlags: a run polls its own stream for `spin_us` before it blocks, see wait_stream)
+    swmi_ctx *c = new swmi_ctx;
     c->device = device;
     e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-    if (e != hipSuccess) return fail(SWMI_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+    if (e != hipSuccess) { c->stream = nullptr; ctx_release(c); return fail(SWMI_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
     for (auto &ev : c->ev) {
         e = hipEventCreate(&ev);
-        if (e != hipSuccess) return fail(SWMI_ERR_HIP, "hipEventCreate: %s", hipGetErrorString(e));
+        if (e != hipSuccess) { ev = nullptr; ctx_release(c); return fail(SWMI_ERR_HIP, "hipEventCreate: %s", hipGetErrorString(e)); }
     }
-    { int r = c->h_err.reserve(64); if (r) return r; }
+    { int r = c->h_err.reserve(64); if (r) { ctx_release(c); return r; } }
     *(volatile uint32_t *)c->h_err.p = 0u;
-    *out = c.release();
+    { int r = c->d_lut.reserve(256); if (r) { ctx_release(c); return r; } }
+    e = hipMemcpy(c->d_lut.p, code_table(), 256, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { ctx_release(c); return fail(SWMI_ERR_HIP, "code table upload: %s", hipGetErrorString(e)); }
+    *out = c;
     return SWMI_OK;
 }
 
@@ -247,14 +278,15 @@ extern "C" void swmi_destroy(swmi_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->worker.joinable()) {
-        while (ctx->job_state.load(std::memory_order_acquire) == 1) std::this_thread::yield();   // a run still in flight
-        ctx->job_state.store(3, std::memory_order_release);
+        {
+            std::unique_lock<std::mutex> lk(ctx->job_mu);
+            ctx->job_cv.wait(lk, [&] { return ctx->job_state.load() != 1; });      // a run still in flight
+            ctx->job_state.store(3);
+        }
+        ctx->job_cv.notify_all();
         ctx->worker.join();
     }
-    for (auto &ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
-    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
-    ctx->h_err.release();
-    delete ctx;
+    ctx_release(ctx);
 }
 
 extern "C" int swmi_set_option(swmi_ctx *ctx, const char *name, int64_t value) {
@@ -267,8 +299,23 @@ extern "C" int swmi_set_option(swmi_ctx *ctx, const char *name, int64_t value) {
         if (value < (1 << 20)) return fail(SWMI_ERR_INVALID, "max_workspace_bytes too small");
         ctx->max_workspace_bytes = (uint64_t)value;
     } else if (!strcmp(name, "mode")) {
-        if (value < 0 || value > 2) return fail(SWMI_ERR_INVALID, "mode must be 0, 1 or 2");
-        ctx->mode = (uint32_t)value;
+        // -1: automatic (the default): mode 1, or mode 0 for batches where most pairs carry many tied maxima
+        if (value < -1 || value > 2) return fail(SWMI_ERR_INVALID, "mode must be -1 (automatic), 0, 1 or 2");
+        ctx->auto_mode = value < 0;
+        ctx->mode = value < 0 ? 1u : (uint32_t)value;
+    } else if (!strcmp(name, "auto_ties_x100")) {
+        if (value < 100) return fail(SWMI_ERR_INVALID, "auto_ties_x100 out of range");
+        ctx->auto_ties_x100 = (uint32_t)value;
+    } else if (!strcmp(name, "spin_us")) {
+        if (value < 0) return fail(SWMI_ERR_INVALID, "spin_us out of range");
+        ctx->spin_us = value;
+    } else if (!strcmp(name, "debug_strip_spins")) {
+        ctx->dbg_strip_spins = (uint32_t)value;
+    } else if (!strcmp(name, "debug_reverse_strips")) {
+        ctx->dbg_reverse_strips = value != 0;
+    } else if (!strcmp(name, "col_chunks")) {
+        if (value < 0 || value > 4096) return fail(SWMI_ERR_INVALID, "col_chunks out of range");
+        ctx->col_chunks = (uint32_t)value;
     } else if (!strcmp(name, "zero_copy")) {
         ctx->zero_copy = value != 0;
     } else if (!strcmp(name, "profiling")) {
@@ -293,8 +340,8 @@ extern "C" int swmi_set_option(swmi_ctx *ctx, const char *name, int64_t value) {
 // runs the compare-and-select variant.
 static const uint8_t *code_table() {
     static uint8_t T[256];
-    static bool init = false;
-    if (!init) {
+    static std::once_flag once;              // MapRef.call runs on every executor thread (Distribution.java:32,403)
+    std::call_once(once, [] {
         uint8_t perm[256];
         for (int i = 0; i < 256; i++) perm[i] = (uint8_t)i;
         const uint8_t fast[8] = {'A', 'C', 'G', 'T', 'N', 'U', 'R', 'Y'};
@@ -304,34 +351,26 @@ static const uint8_t *code_table() {
             if ((i >= 'a' && i <= 'z') || (i >= 0xE0 && i <= 0xFE && i != 0xF7)) u = i - 32;
             T[i] = perm[u];
         }
-        init = true;
-    }
+    });
     return T;
 }
 
-static void encode_sequences(const uint8_t *bytes, const uint64_t *off, uint32_t n,
-                             std::vector<uint32_t> &seqw, std::vector<SeqDesc> &desc) {
-    const uint8_t *T = code_table();
+// Geometry of the byte images (swmi_device.h): every image 16-byte aligned and followed by SWMI_SEQ_PAD_WORDS zero
+// dwords.  The bytes themselves are canonicalised on the GPU (sw_encode_kernel, swmi_prep.hip).
+static uint64_t layout_sequences(const uint64_t *off, uint32_t n, uint64_t word0, std::vector<SeqDesc> &desc) {
     desc.resize(n);
+    uint64_t at = word0;
     for (uint32_t s = 0; s < n; s++) {
         const uint64_t len = off[s + 1] - off[s];
-        const uint8_t *p = bytes + off[s];
+        at = (at + 3) & ~(uint64_t)3;
         SeqDesc d{};
         d.len = (uint32_t)len;
-        seqw.resize((seqw.size() + 3) & ~(size_t)3, 0u);          // 16-byte aligned image (dwordx4 loads)
-        d.boff = (uint32_t)seqw.size();
-        const size_t bw = (len + 3) / 4;
-        seqw.resize(seqw.size() + bw + SWMI_SEQ_PAD_WORDS, 0u);
-        bool acgt = true;
-        uint32_t *bwp = seqw.data() + d.boff;
-        for (uint64_t k = 0; k < len; k++) {
-            const uint32_t c = T[p[k]];
-            acgt &= (c & 0xE3u) == 0;                               // 0, 4, ..., 28
-            bwp[k >> 2] |= c << (8 * (k & 3));
-        }
-        d.acgt = acgt ? 1u : 0u;
+        d.boff = (uint32_t)at;                 // (checked against 2^32 by the caller)
+        d.acgt = 0;                            // set by the encode kernel
         desc[s] = d;
+        at += (len + 3) / 4 + SWMI_SEQ_PAD_WORDS;
     }
+    return at;
 }
 
 static int check_offsets(const uint64_t *off, uint32_t n, const char *what) {
@@ -351,12 +390,49 @@ static int check_offsets(const uint64_t *off, uint32_t n, const char *what) {
 extern "C" void swmi_batch_free(swmi_ctx *ctx, swmi_batch *b) {
     if (!b) return;
     if (ctx) (void)hipSetDevice(ctx->device);
+    b->d_raw.release(); b->d_raw_off.release();
     b->d_seqw.release(); b->d_refs.release(); b->d_reads.release(); b->d_pairs.release();
     b->d_dir.release(); b->d_seam.release(); b->d_result.release(); b->d_cells.release();
     b->d_cells_off.release(); b->d_cells_cap.release(); b->d_dbg.release(); b->d_dbg2.release();
-    b->d_strip_items.release(); b->d_progress.release();
+    b->d_strip_items.release(); b->d_progress.release(); b->d_col_items.release();
     b->h_result.release();
     delete b;
+}
+
+// Device side of an upload: geometry from the offsets already stored in the batch, the raw bytes H2D, and the
+// canonical images written by sw_encode_kernel.  `ref_src` / `read_src` may be pinned (the streaming path) or pageable.
+// Enqueued on `st` and synchronised before returning.
+static int upload_device(swmi_ctx *ctx, swmi_batch *b, hipStream_t st, const uint8_t *ref_src, const uint8_t *read_src) {
+    const uint32_t n_refs = b->n_refs, n_reads = b->n_reads;
+    const uint64_t ref_total = b->ref_off[n_refs], read_total = b->read_off[n_reads];
+    uint64_t words = layout_sequences(b->ref_off.data(), n_refs, 0, b->ref_desc);
+    words = layout_sequences(b->read_off.data(), n_reads, words, b->read_desc);
+    words = ((words + 3) & ~(uint64_t)3) + SWMI_SEQ_PAD_WORDS;
+    if (words >= (1ull << 32)) return fail(SWMI_ERR_UNSUPPORTED, "sequence image exceeds 16 GiB");
+    int rc;
+    const uint64_t read_base = (ref_total + 15) & ~(uint64_t)15;
+    if ((rc = b->d_seqw.reserve(words * 4))) return rc;
+    if ((rc = b->d_raw.reserve(read_base + read_total + 16))) return rc;
+    if ((rc = b->d_raw_off.reserve(((uint64_t)n_refs + n_reads + 2) * 8))) return rc;
+    if ((rc = b->d_refs.reserve(std::max<size_t>(n_refs, 1) * sizeof(SeqDesc)))) return rc;
+    if ((rc = b->d_reads.reserve(std::max<size_t>(n_reads, 1) * sizeof(SeqDesc)))) return rc;
+    HIP_TRY(hipMemsetAsync(b->d_seqw.p, 0, words * 4, st));
+    uint8_t *raw = b->d_raw.as<uint8_t>();
+    uint64_t *roff = b->d_raw_off.as<uint64_t>();
+    if (ref_total) HIP_TRY(hipMemcpyAsync(raw, ref_src, ref_total, hipMemcpyHostToDevice, st));
+    if (read_total) HIP_TRY(hipMemcpyAsync(raw + read_base, read_src, read_total, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(roff, b->ref_off.data(), ((size_t)n_refs + 1) * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(roff + n_refs + 1, b->read_off.data(), ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice, st));
+    if (n_refs) HIP_TRY(hipMemcpyAsync(b->d_refs.p, b->ref_desc.data(), n_refs * sizeof(SeqDesc), hipMemcpyHostToDevice, st));
+    if (n_reads) HIP_TRY(hipMemcpyAsync(b->d_reads.p, b->read_desc.data(), n_reads * sizeof(SeqDesc), hipMemcpyHostToDevice, st));
+    HIP_TRY(swmi_launch_encode(raw, roff, b->d_refs.as<SeqDesc>(), b->d_seqw.as<uint32_t>(), ctx->d_lut.as<uint8_t>(), n_refs, st));
+    HIP_TRY(swmi_launch_encode(raw + read_base, roff + n_refs + 1, b->d_reads.as<SeqDesc>(), b->d_seqw.as<uint32_t>(),
+                               ctx->d_lut.as<uint8_t>(), n_reads, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    // a new set of sequences invalidates everything derived from the old one
+    b->work_mode = -1; b->prep.valid = false; b->pairs_dev_ptr = nullptr; b->pairs_on_device.clear();
+    b->has_run = false; b->acgt_known = false; b->auto_choice = -1;
+    return SWMI_OK;
 }
 
 extern "C" int swmi_batch_upload(swmi_ctx *ctx,
@@ -379,27 +455,11 @@ extern "C" int swmi_batch_upload(swmi_ctx *ctx,
     b->n_refs = n_refs; b->n_reads = n_reads;
     b->ref_off.assign(ref_off, ref_off + n_refs + 1);
     b->read_off.assign(read_off, read_off + n_reads + 1);
+    // the caller's buffers are only valid during this call: the original bytes are kept for the alignment strings
+    // (characters keep their case, SmithWaterman.java:388-406)
     b->ref_bytes.assign(ref_bytes, ref_bytes + ref_off[n_refs]);
     b->read_bytes.assign(read_bytes, read_bytes + read_off[n_reads]);
-
-    std::vector<uint32_t> seqw;
-    seqw.reserve((ref_off[n_refs] + read_off[n_reads]) / 3 + 16ull * (n_refs + n_reads) + 16);
-    encode_sequences(ref_bytes, ref_off, n_refs, seqw, b->ref_desc);
-    encode_sequences(read_bytes, read_off, n_reads, seqw, b->read_desc);
-    if (seqw.size() >= (1ull << 32)) return fail(SWMI_ERR_UNSUPPORTED, "sequence image exceeds 16 GiB");
-    seqw.resize(seqw.size() + SWMI_SEQ_PAD_WORDS, 0u);
-
-    auto up = [&](DevBuf &d, const void *src, size_t bytes) -> int {
-        int r = d.reserve(bytes ? bytes : 4);
-        if (r) return r;
-        if (bytes) HIP_TRY(hipMemcpyAsync(d.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
-        return SWMI_OK;
-    };
-    if ((rc = up(b->d_seqw, seqw.data(), seqw.size() * 4))) { swmi_batch_free(ctx, b.release()); return rc; }
-    if ((rc = up(b->d_refs, b->ref_desc.data(), b->ref_desc.size() * sizeof(SeqDesc)))) { swmi_batch_free(ctx, b.release()); return rc; }
-    if ((rc = up(b->d_reads, b->read_desc.data(), b->read_desc.size() * sizeof(SeqDesc)))) { swmi_batch_free(ctx, b.release()); return rc; }
-    hipError_t e = hipStreamSynchronize(ctx->stream);
-    if (e != hipSuccess) { swmi_batch_free(ctx, b.release()); return fail(SWMI_ERR_HIP, "upload sync: %s", hipGetErrorString(e)); }
+    if ((rc = upload_device(ctx, b.get(), ctx->stream, ref_bytes, read_bytes))) { swmi_batch_free(ctx, b.release()); return rc; }
     *out = b.release();
     return SWMI_OK;
 }
@@ -417,6 +477,7 @@ struct RunState {
     float fill_ms = 0, tb_ms = 0, d2h_ms = 0;
     uint32_t launches = 0;
     double enqueue_us = 0, wait_us = 0, copyout_us = 0;
+    bool one_wave_sweep = false;            // the strip pipeline gave up once in this run: long reads are swept by one wavefront
 };
 
 // layout of the device result block: [ArenaHdr | PairOut x np | arena words ...]
@@ -459,17 +520,33 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
     // pair descriptors, direction-field and seam offsets
     std::vector<PairDesc> pd;
     std::vector<uint2> strip_items;          // mode 1: (pair, strip) of every read longer than one strip, one wavefront each
+    std::vector<ColItem> col_items;          // mode 1: column chunks of single-strip pairs when the launch has few pairs
     uint64_t dir_words = 0, seam_words = 0;
     uint32_t max_path = 0, max_read = 0;
-    size_t n_strip_items = 0;
+    size_t n_strip_items = 0, n_col_items = 0;
     swmi_batch::Prep &pr = b->prep;
     const bool prepared = pr.valid && pr.lo == lo && pr.hi == hi && pr.work == (const void *)work.data() && pr.mode == b->eff_mode &&
                           memcmp(&pr.params, &b->params, sizeof(swmi_params)) == 0 && b->pairs_dev_ptr == b->d_pairs.p &&
-                          b->pairs_on_device.size() == np * sizeof(PairDesc);
+                          b->pairs_on_device.size() == np * sizeof(PairDesc) && pr.col_chunks_opt == ctx->col_chunks &&
+                          pr.reverse_strips == (ctx->dbg_reverse_strips != 0);
     if (prepared) {
         dir_words = pr.dir_words; seam_words = pr.seam_words; max_path = pr.max_path; max_read = pr.max_read;
-        n_strip_items = pr.n_strip_items;
+        n_strip_items = pr.n_strip_items; n_col_items = pr.n_col_items;
     } else {
+    // Column chunks (swmi_device.h: ColItem): a launch of few pairs leaves most of the 1024 SIMDs idle while every pair is
+    // one dependent chain of n + 63 steps.  A positive-score path spans at most m + match*m/|gap| columns (A <= m
+    // alignment moves, and match*A + gap*D > 0 bounds the deletions D), so a wavefront that starts that far to the left of
+    // a window computes the window exactly: the reference is cut into chunks of windows, one wavefront each.
+    const swmi_params &P = b->params;
+    const bool cols_possible = b->eff_mode == 1 && P.match > 0 && P.gap < 0 && P.mismatch <= 0 &&
+                               P.match <= 7 && P.mismatch >= -8 && (np <= 512 || ctx->col_chunks > 1) && ctx->col_chunks != 1;
+    if (cols_possible && !b->acgt_known) {
+        // the fast-symbol flags are derived on the device by the encode kernel
+        if (b->n_refs) HIP_TRY(hipMemcpy(b->ref_desc.data(), b->d_refs.p, b->n_refs * sizeof(SeqDesc), hipMemcpyDeviceToHost));
+        if (b->n_reads) HIP_TRY(hipMemcpy(b->read_desc.data(), b->d_reads.p, b->n_reads * sizeof(SeqDesc), hipMemcpyDeviceToHost));
+        b->acgt_known = true;
+    }
+    const uint64_t chunk_budget = ctx->col_chunks > 1 ? ctx->col_chunks : std::max<uint64_t>(1, 1024 / std::max<size_t>(np, 1));
     pd.resize(np);
     for (size_t k = 0; k < np; k++) {
         const Work &w = work[lo + k];
@@ -481,16 +558,43 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
         d.seam_off = seam_words;
         dir_words += w.dir_words;
         seam_words += w.seam_words;
-        if (b->eff_mode == 1 && b->read_desc[d.read_id].len > 64u * SWMI_RMAX && strip_items.size() < (1u << 30)) {
-            const uint32_t strips = (b->read_desc[d.read_id].len + 64u * SWMI_RMAX - 1u) / (64u * SWMI_RMAX);
+        const uint32_t m_ = b->read_desc[d.read_id].len, n_ = b->ref_desc[d.ref_id].len;
+        if (b->eff_mode == 1 && m_ > 64u * SWMI_RMAX && strip_items.size() < (1u << 30)) {
+            const uint32_t strips = (m_ + 64u * SWMI_RMAX - 1u) / (64u * SWMI_RMAX);
             d.pad = (uint32_t)strip_items.size();
-            for (uint32_t st = 0; st < strips; st++) strip_items.push_back(make_uint2((uint32_t)k, st));
+            if (ctx->dbg_reverse_strips) for (uint32_t st = strips; st-- > 0;) strip_items.push_back(make_uint2((uint32_t)k, st));
+            else                         for (uint32_t st = 0; st < strips; st++) strip_items.push_back(make_uint2((uint32_t)k, st));
+        } else if (cols_possible && chunk_budget > 1 && m_ <= 64u * SWMI_RMAX && b->read_desc[d.read_id].acgt && b->ref_desc[d.ref_id].acgt) {
+            const uint64_t span = (uint64_t)m_ + (uint64_t)P.match * m_ / (uint64_t)(-(int64_t)P.gap) + 1;   // columns a path can span
+            const uint64_t wblocks = ((uint64_t)n_ + 63u + 15u) / 16u;
+            const uint32_t n_ck = (uint32_t)((wblocks + SWMI_CK_BLOCKS - 1u) / SWMI_CK_BLOCKS);
+            const uint32_t step_w = 16u * SWMI_CK_BLOCKS;                       // anti-diagonal steps (= columns of lane 0) per window
+            uint64_t chunks = std::min<uint64_t>(chunk_budget, n_ / std::max<uint64_t>(span + 64, 256));
+            chunks = std::min<uint64_t>(chunks, n_ck);
+            if (chunks >= 2) {
+                const uint32_t wpc = (uint32_t)((n_ck + chunks - 1) / chunks);   // windows per chunk
+                const size_t first = col_items.size();
+                for (uint32_t g_lo = 0; g_lo < n_ck; g_lo += wpc) {
+                    ColItem ci;
+                    ci.pair = (uint32_t)k;
+                    ci.g_lo = g_lo;
+                    ci.g_hi = std::min(g_lo + wpc, n_ck);
+                    // a chunk that is not the last must end where lane 0 is still inside the reference
+                    if (ci.g_hi < n_ck && (uint64_t)ci.g_hi * step_w > n_) ci.g_hi = n_ck;
+                    const int64_t c0 = (int64_t)g_lo * step_w - 64 - (int64_t)span - 1;
+                    ci.col0 = g_lo == 0 || c0 <= 0 ? 0u : (uint32_t)(c0 & ~(int64_t)31);
+                    col_items.push_back(ci);
+                    if (ci.g_hi == n_ck) break;
+                }
+                d.pad = SWMI_PAD_COLS | (uint32_t)(col_items.size() - first);
+            }
         }
         pd[k] = d;
-        max_path = std::max<uint32_t>(max_path, (uint32_t)path_bound(b->ref_desc[d.ref_id].len, b->read_desc[d.read_id].len, b->params));
-        max_read = std::max(max_read, b->read_desc[d.read_id].len);
+        max_path = std::max<uint32_t>(max_path, (uint32_t)path_bound(n_, m_, b->params));
+        max_read = std::max(max_read, m_);
     }
     n_strip_items = strip_items.size();
+    n_col_items = col_items.size();
     }
     if ((rc = b->d_pairs.reserve(np * sizeof(PairDesc)))) return rc;
     if (!prepared && !strip_items.empty()) {
@@ -498,6 +602,11 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
         if ((rc = b->d_progress.reserve(strip_items.size() * sizeof(uint32_t)))) return rc;
         HIP_TRY(hipMemcpyAsync(b->d_strip_items.p, strip_items.data(), strip_items.size() * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));      // strip_items is a local
+    }
+    if (!prepared && !col_items.empty()) {
+        if ((rc = b->d_col_items.reserve(col_items.size() * sizeof(ColItem)))) return rc;
+        HIP_TRY(hipMemcpyAsync(b->d_col_items.p, col_items.data(), col_items.size() * sizeof(ColItem), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));      // col_items is a local
     }
     if ((rc = b->d_dir.reserve(std::max<uint64_t>(dir_words, 1) * 4))) return rc;
     if ((rc = b->d_seam.reserve(std::max<uint64_t>(seam_words, 1) * 4))) return rc;
@@ -513,7 +622,8 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
         pr.valid = b->pairs_dev_ptr == b->d_pairs.p;
         pr.lo = lo; pr.hi = hi; pr.work = (const void *)work.data(); pr.params = b->params; pr.mode = b->eff_mode;
         pr.dir_words = dir_words; pr.seam_words = seam_words; pr.max_path = max_path; pr.max_read = max_read;
-        pr.n_strip_items = n_strip_items;
+        pr.n_strip_items = n_strip_items; pr.n_col_items = n_col_items;
+        pr.col_chunks_opt = ctx->col_chunks; pr.reverse_strips = ctx->dbg_reverse_strips != 0;
     }
     if (seam_words) HIP_TRY(hipMemsetAsync(b->d_seam.p, 0, seam_words * 4, ctx->stream));
 
@@ -586,12 +696,17 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
         fa.match = b->params.match; fa.mismatch = b->params.mismatch; fa.gap = b->params.gap;
         fa.strict = b->params.tie_mode == SWMI_TIE_STRICT;
         fa.mode = b->eff_mode;
-        fa.skip_multi = n_strip_items ? 1u : 0u;
-        fa.strip_items = n_strip_items ? b->d_strip_items.as<uint2>() : nullptr;
-        fa.progress = n_strip_items ? b->d_progress.as<uint32_t>() : nullptr;
-        fa.n_strip_items = (uint32_t)n_strip_items;
+        const bool pipe = n_strip_items && !rs.one_wave_sweep;
+        fa.skip_multi = pipe ? 1u : 0u;
+        fa.strip_items = pipe ? b->d_strip_items.as<uint2>() : nullptr;
+        fa.progress = pipe ? b->d_progress.as<uint32_t>() : nullptr;
+        fa.n_strip_items = pipe ? (uint32_t)n_strip_items : 0u;
         fa.err_host = (uint32_t *)ctx->h_err.dp;
         fa.pad3 = 0;
+        if (attempt == 0) b->timing.col_chunks += (uint32_t)n_col_items;
+        fa.col_items = n_col_items ? b->d_col_items.as<ColItem>() : nullptr;
+        fa.n_col_items = (uint32_t)n_col_items;
+        fa.strip_spins = ctx->dbg_strip_spins;
 
         TraceArgs &ta = rs.ta;
         ta.seqw = fa.seqw; ta.refs = fa.refs; ta.reads = fa.reads; ta.pairs = fa.pairs;
@@ -646,11 +761,25 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
             if (ctx->profiling) HIP_TRY(hipEventRecord(ctx->ev[4], ctx->stream));
         }
         const auto c1 = std::chrono::steady_clock::now();
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        {   // a batch is sub-millisecond: poll the stream for spin_us (this context only, no process-wide spin flag), then block
+            hipError_t q = hipErrorNotReady;
+            while (ctx->spin_us > 0 && (q = hipStreamQuery(ctx->stream)) == hipErrorNotReady &&
+                   std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - c1).count() < (double)ctx->spin_us)
+                __builtin_ia32_pause();
+            if (q != hipSuccess && q != hipErrorNotReady) return fail(SWMI_ERR_HIP, "hipStreamQuery: %s", hipGetErrorString(q));
+            if (q != hipSuccess) HIP_TRY(hipStreamSynchronize(ctx->stream));
+        }
         const auto c2 = std::chrono::steady_clock::now();
         if (*(volatile uint32_t *)ctx->h_err.p != 0u) {
+            // a strip of the pipelined sweep gave up waiting for its producer wavefront (it was not dispatched, or did not
+            // move for the whole spin budget): nothing of this launch is used.  The chunk is swept again with ONE wavefront
+            // per pair, strip after strip -- no wavefront of that sweep waits for another workgroup.
             *(volatile uint32_t *)ctx->h_err.p = 0u;
-            return fail(SWMI_ERR_HIP, "the strip pipeline of the sweep timed out waiting for a producer wavefront; results discarded");
+            if (rs.one_wave_sweep)
+                return fail(SWMI_ERR_HIP, "the sweep raised its error flag without the strip pipeline; results discarded");
+            rs.one_wave_sweep = true;
+            b->timing.strip_fallbacks++;
+            return run_chunk(rs, work, lo, hi, cells_exact, outs, arena_copy, arena_used);
         }
         rs.enqueue_us += std::chrono::duration<double, std::micro>(c1 - c0).count();
         rs.wait_us += std::chrono::duration<double, std::micro>(c2 - c1).count();
@@ -850,7 +979,45 @@ extern "C" int swmi_batch_run(swmi_ctx *ctx, swmi_batch *b, const swmi_params *p
     // pairs with an empty side never enter ScoreMatrix's loops (SmithWaterman.java:157-159): (0, [])
     // The schedule only depends on the sequence lengths and the pipeline mode: built once per batch.
     // mode 1 needs pad rows that cannot outgrow the real cells they derive from: mismatch <= 0 and gap <= 0
-    b->eff_mode = (ctx->mode == 1 && (p->mismatch > 0 || p->gap > 0)) ? 2u : ctx->mode;
+    uint32_t want_mode = ctx->mode;
+    if (ctx->auto_mode && b->auto_choice >= 0 && memcmp(&b->auto_params, p, sizeof(swmi_params)) == 0) want_mode = (uint32_t)b->auto_choice;
+    b->eff_mode = (want_mode == 1 && (p->mismatch > 0 || p->gap > 0)) ? 2u : want_mode;
+    if (ctx->auto_mode && b->eff_mode == 1 && n_pairs >= 64 &&
+        (b->auto_choice < 0 || memcmp(&b->auto_params, p, sizeof(swmi_params)) != 0)) {
+        // Automatic pipeline choice, once per batch and parameter set: a sample of the pairs is aligned in mode 1 and
+        // the tied maxima per pair are counted.  Periodic references (the reference's own EngineerData sets: every period
+        // ends in a tied maximum, EngineerData.java:118) make the per-path window re-sweeps of mode 1 cost more than
+        // writing the whole direction field once (mode 0).
+        std::vector<Work> sample;
+        const uint64_t want = 48, stride = std::max<uint64_t>(1, n_pairs / want);
+        for (uint64_t pi = stride / 2; pi < n_pairs && sample.size() < want; pi += stride) {
+            const uint32_t m = b->read_desc[pi % n_reads].len, n = b->ref_desc[pi / n_reads].len;
+            if (m == 0 || n == 0) continue;
+            Work w;
+            w.pair = (uint32_t)pi; w.cells = (uint64_t)m * n;
+            w.dir_words = swmi_dir_words(m, n, 1); w.seam_words = swmi_seam_words(m, n);
+            sample.push_back(w);
+        }
+        int choice = 1;
+        if (!sample.empty()) {
+            RunState rs0;
+            rs0.ctx = ctx; rs0.b = b;
+            std::vector<PairOut> o0;
+            std::vector<uint32_t> a0;
+            uint64_t u0 = 0;
+            int rc = run_chunk(rs0, sample, 0, sample.size(), nullptr, o0, a0, u0);
+            if (rc) return rc;
+            uint64_t cells = 0, live = 0;
+            for (auto &o : o0)
+                if (!(o.flags & SWMI_F_DEGENERATE)) { cells += std::min<uint64_t>(o.n_cells, ctx->cell_cap); live++; }
+            if (live && cells * 100 >= (uint64_t)ctx->auto_ties_x100 * live) choice = 0;
+            b->prep.valid = false;                    // (the cached preparation was the sample's)
+            b->timing = swmi_timing{};
+        }
+        b->auto_choice = choice;
+        b->auto_params = *p;
+        b->eff_mode = (uint32_t)choice;
+    }
     if (b->eff_mode == 0) {
         // mode 0's 256-step direction tiles leave the least LDS for the staged alignment: batches with pairs too long for
         // it run as mode 1 (or 2) -- the results are the same
@@ -967,16 +1134,20 @@ extern "C" int swmi_batch_run(swmi_ctx *ctx, swmi_batch *b, const swmi_params *p
 // without a wake-up latency, and sleeps when the context stays idle.
 static void swmi_worker_loop(swmi_ctx *ctx) {
     for (;;) {
-        int st, idle = 0;
-        while ((st = ctx->job_state.load(std::memory_order_acquire)) != 1) {
-            if (st == 3) return;
-            if (++idle < 20000) { __builtin_ia32_pause(); }
-            else std::this_thread::sleep_for(std::chrono::microseconds(50));
+        int st = 0;
+        for (int spin = 0; spin < 4000 && (st = ctx->job_state.load(std::memory_order_acquire)) != 1 && st != 3; ++spin)
+            __builtin_ia32_pause();                  // back-to-back runs start without a wake-up; an idle context blocks
+        if (st != 1 && st != 3) {
+            std::unique_lock<std::mutex> lk(ctx->job_mu);
+            ctx->job_cv.wait(lk, [&] { const int v = ctx->job_state.load(); return v == 1 || v == 3; });
+            st = ctx->job_state.load();
         }
+        if (st == 3) return;
         const int rc = swmi_batch_run(ctx, ctx->job_batch, &ctx->job_params);
         ctx->job_rc = rc;
         ctx->job_err = rc ? swmi_last_error() : "";
-        ctx->job_state.store(2, std::memory_order_release);
+        { std::lock_guard<std::mutex> lk(ctx->job_mu); ctx->job_state.store(2, std::memory_order_release); }
+        ctx->job_cv.notify_all();
     }
 }
 
@@ -987,7 +1158,8 @@ extern "C" int swmi_batch_run_async(swmi_ctx *ctx, swmi_batch *b, const swmi_par
     if (!ctx->worker.joinable()) ctx->worker = std::thread(swmi_worker_loop, ctx);
     ctx->job_batch = b;
     ctx->job_params = *p;
-    ctx->job_state.store(1, std::memory_order_release);
+    { std::lock_guard<std::mutex> lk(ctx->job_mu); ctx->job_state.store(1, std::memory_order_release); }
+    ctx->job_cv.notify_all();
     return SWMI_OK;
 }
 
@@ -995,15 +1167,25 @@ extern "C" int swmi_batch_wait(swmi_ctx *ctx) {
     if (!ctx) return fail(SWMI_ERR_INVALID, "null argument");
     int st = ctx->job_state.load(std::memory_order_acquire);
     if (st == 0) return fail(SWMI_ERR_INVALID, "no run in flight on this context");
-    int spins = 0;
-    while (st != 2) {
-        if (++spins < 200000) __builtin_ia32_pause(); else std::this_thread::yield();
+    for (int spin = 0; spin < 20000 && st != 2; ++spin) {           // a short bounded spin, then block
+        __builtin_ia32_pause();
         st = ctx->job_state.load(std::memory_order_acquire);
+    }
+    if (st != 2) {
+        std::unique_lock<std::mutex> lk(ctx->job_mu);
+        ctx->job_cv.wait(lk, [&] { return ctx->job_state.load() == 2; });
     }
     const int rc = ctx->job_rc;
     const std::string err = ctx->job_err;
     ctx->job_state.store(0, std::memory_order_release);
     if (rc) return fail(rc, "%s", err.c_str());
+    return SWMI_OK;
+}
+
+extern "C" int swmi_batch_mode(const swmi_batch *b, int *mode) {
+    if (!b || !mode) return fail(SWMI_ERR_INVALID, "null argument");
+    if (!b->has_run) return fail(SWMI_ERR_INVALID, "batch has no results (run it first)");
+    *mode = (int)b->eff_mode;
     return SWMI_OK;
 }
 
@@ -1048,6 +1230,19 @@ extern "C" int swmi_pair_n_alignments(const swmi_batch *b, uint64_t pair, uint64
     if (rc) return rc;
     if (n) *n = b->pairs[pair].n_cells;
     if (flags) *flags = b->pairs[pair].flags;
+    return SWMI_OK;
+}
+
+// every pair's score and alignment count at once (bulk form of the two accessors above)
+extern "C" int swmi_batch_pair_results(const swmi_batch *b, int32_t *scores, uint64_t *n_alignments, uint64_t n) {
+    if (!b) return fail(SWMI_ERR_INVALID, "batch is null");
+    if (!b->has_run) return fail(SWMI_ERR_INVALID, "batch has no results (run it first)");
+    if (n != (uint64_t)b->n_refs * b->n_reads) return fail(SWMI_ERR_RANGE, "the batch has %llu pairs, not %llu",
+                                                           (unsigned long long)b->n_refs * b->n_reads, (unsigned long long)n);
+    for (uint64_t k = 0; k < n; k++) {
+        if (scores) scores[k] = b->pairs[k].score;
+        if (n_alignments) n_alignments[k] = b->pairs[k].n_cells;
+    }
     return SWMI_OK;
 }
 
@@ -1100,6 +1295,30 @@ extern "C" int swmi_pair_alignment(swmi_batch *b, uint64_t pair, uint64_t k,
     if (ref_aln) *ref_aln = b->str_ref[a.str_id].c_str();
     if (read_aln) *read_aln = b->str_read[a.str_id].c_str();
     if (len) *len = a.n_ops;
+    return SWMI_OK;
+}
+
+// Everything OptAlignments returns for every pair of the batch, built in one call: record index + both strings of every
+// alignment (SmithWaterman.java:418-431).  The accessors above then only hand out pointers.
+extern "C" int swmi_batch_materialise_all(swmi_batch *b, uint64_t *n_alignments, uint64_t *n_chars) {
+    if (!b) return fail(SWMI_ERR_INVALID, "batch is null");
+    if (!b->has_run) return fail(SWMI_ERR_INVALID, "batch has no results (run it first)");
+    int rc = ensure_indexed(b);
+    if (rc) return rc;
+    uint64_t na = 0, nc = 0;
+    const uint64_t np = (uint64_t)b->n_refs * b->n_reads;
+    for (uint64_t pair = 0; pair < np; pair++) {
+        PairRes &pr = b->pairs[pair];
+        if (pr.flags & SWMI_PAIR_DEGENERATE) { na += pr.n_cells; continue; }     // (0, "", "") each: nothing to build
+        for (uint64_t k = 0; k < pr.count; k++) {
+            HostAln &a = b->alns[pr.first + k];
+            if (a.str_id < 0) materialise(b, pair, a, pr.first + k);
+            nc += 2ull * a.n_ops;
+        }
+        na += pr.count;
+    }
+    if (n_alignments) *n_alignments = na;
+    if (n_chars) *n_chars = nc;
     return SWMI_OK;
 }
 

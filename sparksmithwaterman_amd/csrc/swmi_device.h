@@ -59,6 +59,19 @@ struct PairDesc {
     uint64_t seam_off;    // dword offset of the strip-seam rows, n+1 int32 per strip (multi-strip pairs only)
 };
 
+// PairDesc.pad of a single-strip pair whose sweep is split into column chunks (mode 1): this flag + the number of chunks
+#define SWMI_PAD_COLS 0x80000000u
+
+// One column chunk of a pair's mode-1 sweep (sw_sweep_winmax_cols_kernel): the wavefront starts a fresh sweep at
+// reference column col0 + 1 (col0 a multiple of 32) -- far enough to the left that every cell from checkpoint window
+// g_lo on is exact, because a positive-score path cannot span more columns than that -- and owns the checkpoint
+// windows g_lo .. g_hi-1: it writes exactly the checkpoints and window maxima a one-wavefront sweep would have written.
+struct ColItem {
+    uint32_t pair;        // index into FillArgs.pairs
+    uint32_t col0;
+    uint32_t g_lo, g_hi;
+};
+
 struct PairOut {
     int32_t  score;
     uint32_t flags;
@@ -108,6 +121,9 @@ struct FillArgs {
     uint32_t        n_strip_items;
     uint32_t        pad3;
     uint32_t       *err_host;    // host-mapped word, set to 1 when a strip gave up waiting for its producer
+    const ColItem  *col_items;   // mode 1: column chunks of single-strip pairs (few pairs, long references)
+    uint32_t        n_col_items;
+    uint32_t        strip_spins; // spin budget of the strip pipeline before it gives up (0: default)
 };
 
 struct TraceArgs {

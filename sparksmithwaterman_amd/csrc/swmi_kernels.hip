@@ -457,12 +457,19 @@ __device__ __forceinline__ void fill_pair(const FillArgs &A, const PairDesc pd, 
         auto load_seam = [&](uint32_t tb) -> int {
             if (PIPE) {
                 const uint32_t need = tb + 5u < nblk_prod ? tb + 5u : nblk_prod;
-                uint32_t spins = 0;
-                while (!gave_up && __hip_atomic_load(progress + (s - 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+                // the give-up is progress-based: the budget (~60 ms of s_sleep by default) restarts whenever the producer
+                // advances, so a slow producer is waited for and only one that does not move at all is abandoned -- the host
+                // then re-runs the chunk with the one-wavefront sweep, which needs no other workgroup (swmi_api.cpp)
+                const uint32_t budget = A.strip_spins ? A.strip_spins : (1u << 18);
+                uint32_t spins = 0, seen = 0xFFFFFFFFu;
+                while (!gave_up) {
+                    const uint32_t p = __hip_atomic_load(progress + (s - 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (p >= need) break;
+                    if (p != seen) { seen = p; spins = 0; }
                     __builtin_amdgcn_s_sleep(8);
-                    if (++spins > (1u << 18)) {                  // a producer that never comes (~60 ms): an error beats a hung GPU
+                    if (++spins > budget) {
                         gave_up = true;
-                        if (lane == 0 && A.err_host) *A.err_host = 1u;         // the host discards the run (swmi_api.cpp)
+                        if (lane == 0 && A.err_host) *A.err_host = 1u;
                     }
                 }
             }
@@ -551,6 +558,173 @@ __device__ __forceinline__ void fill_pair(const FillArgs &A, const PairDesc pd, 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// mode-1 sweep, fast symbols, one strip (m <= 256): the headline path.  Same results, checkpoints and window maxima
+// as fill_pair<..., SWMI_MODE_WINMAX>, from a shorter instruction stream (tools/gen_step.py: 3 VALU per cell, the
+// neighbour exchanges folded into DPP arithmetic, 14.5 instructions per step at R = 3 instead of 17.8).
+// COLS: this wavefront sweeps only the column chunk `ci` of the pair (swmi_device.h: ColItem).
+// ------------------------------------------------------------------------------------------------
+#include "swmi_step_gen.inc"   // SweepStep4Asm<R>: four steps per asm statement
+
+template <int R>
+struct SweepState {
+    int h[R], g[R];      // H of the lane's rows: h is read by even steps and written by odd ones, g the other way round
+    int hp[R];           // max(H + gap, 0) of the same rows, updated in place
+    int q[R];            // the row's 8 x int4 score profile
+    int rbx, rby;        // one-hot reference symbol: rbx is what an even step consumes (it prepares rby for the odd one)
+    int lmax;            // this lane's maximum H since the last window boundary
+};
+
+// plain statement of one step of SweepStep4Asm::run.  Used for the blocks in which some lane has run past the last column
+// (`in_range` false: the lane keeps its state), and for every block when built with -DSWMI_NO_ASM.
+template <int R>
+__device__ __forceinline__ void sweep_step_ref(const int (&hin)[R], int (&hout)[R], int (&hp)[R], const int (&q)[R],
+                                               const int rb, int &rbn, const uint32_t feed_code, const uint32_t gm,
+                                               int &lm, const bool in_range) {
+    const int nw = wave_shr1_zero(hout[R - 1]);      // lane l-1's bottom row two steps ago = NW of row 0 (lane 0: 0)
+    const int upp = wave_shr1_zero(hp[R - 1]);       // max(N + gap, 0) of row 0 (lane 0: 0)
+    if (in_range) {
+        int diag = nw, up = upp;
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const int a = __builtin_amdgcn_sdot8(q[k], rb, diag, false);    // SmithWaterman.java:244 (AlignmentScore :309-318)
+            diag = hin[k];
+            int hv = a > up ? a : up;                                         // :227-240: max(W + gap, N + gap, 0) is max(hp, hp)
+            hv = hv > hp[k] ? hv : hp[k];
+            hout[k] = hv;
+            hp[k] = (uint32_t)hv > gm ? (int)((uint32_t)hv - gm) : 0;
+            up = hp[k];
+            lm = lm > hv ? lm : hv;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < R; ++k) hout[k] = hin[k];
+    }
+    rbn = wave_shr1((int)(1u << (feed_code & 31u)), rb);
+}
+
+template <int R, bool COLS>
+__device__ __forceinline__ void sweep_fast(const FillArgs &A, const PairDesc pd, const uint32_t lane, const ColItem ci) {
+    const SeqDesc rd = A.refs[pd.ref_id];
+    const SeqDesc qd = A.reads[pd.read_id];
+    const uint32_t n_full = rd.len, m = qd.len;
+    const StripGeom G = strip_geom<R>(m, n_full, 1u);
+    const uint32_t col0 = COLS ? ci.col0 : 0u;
+    const uint32_t g_lo = COLS ? ci.g_lo : 0u, g_hi = COLS ? ci.g_hi : G.n_ck;
+    const bool last = g_hi >= G.n_ck;
+    const uint32_t n = (last ? n_full : 32u * g_hi) - col0;               // columns of this wavefront's (virtual) reference
+    const uint32_t *__restrict__ refw = A.seqw + rd.boff + (col0 >> 2);
+    const uint32_t *__restrict__ readw = A.seqw + qd.boff;
+    const uint32_t lact = m >= G.rps ? WAVE : (m + R - 1) / R;           // lanes holding rows
+    const uint32_t lane_eff = lane < lact ? lane : 0x40000000u;
+    const uint32_t T = n + lact - 1;
+    const uint32_t nblk = last ? (T + 15u) / 16u : n / 16u;               // (a chunk that is not the last ends on a window boundary)
+    const uint32_t gm = (uint32_t)(-(int64_t)A.gap);                      // mode 1: gap <= 0
+    const int one = 1;
+    int pair_max = 0;
+
+    SweepState<R> S;
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const uint32_t row = lane * R + k;
+        uint32_t p = (uint32_t)(A.mismatch & 0xF) * 0x11111111u;
+        if (row < m) {
+            const uint32_t c = seq_code(readw, row);      // 0, 4, ..., 28
+            p = (p & ~(0xFu << c)) | ((uint32_t)(A.match & 0xF) << c);
+        }
+        S.q[k] = (int)p;
+        S.h[k] = 0; S.g[k] = 0; S.hp[k] = 0;
+    }
+    S.lmax = -1;
+    const uint4 *__restrict__ refq = reinterpret_cast<const uint4 *>(refw);   // 16-byte aligned: col0 is a multiple of 32
+    uint4 wnext = refq[0];
+    S.rby = 0;
+    S.rbx = wave_shr1((int)(1u << (wnext.x & 31u)), 0);                   // lane 0: column 1; nothing has flowed further yet
+
+    uint32_t *__restrict__ wsp = A.dir + pd.dir_off + lane;
+    auto close_window = [&](uint32_t g) {
+        const int wm = wave_max_i32(lane < lact ? S.lmax : -1);
+        if (lane == 0) A.dir[pd.dir_off + G.wmax_off + g] = (uint32_t)wm;
+        pair_max = pair_max > wm ? pair_max : wm;
+        S.lmax = -1;
+    };
+    for (uint32_t tb = 0; tb < nblk; ++tb) {
+        const uint4 w = wnext;                            // base codes of (local) columns 16tb+1 .. 16tb+16
+        wnext = refq[tb + 1];                             // prefetch (images are padded)
+        const uint32_t tbg = tb + (col0 >> 4);            // the block's number in the pair's own sweep
+        if ((tbg % SWMI_CK_BLOCKS) == 0u) {
+            const uint32_t g = tbg / SWMI_CK_BLOCKS;
+            if (tb > 0u) {
+                if (g > g_lo) close_window(g - 1u); else S.lmax = -1;
+            }
+            if (g >= g_lo) {
+                // checkpoint in the layout the replay expects: H of the rows, the N received one step earlier, the
+                // reference operand of the last step ([ck][slot][lane], 256 B stores)
+                uint32_t *__restrict__ ck = wsp + (uint64_t)g * (R + 2) * WAVE;
+#pragma unroll
+                for (int k = 0; k < R; ++k) ck[k * WAVE] = (uint32_t)S.h[k];
+                ck[R * WAVE] = (uint32_t)wave_shr1_zero(S.g[R - 1]);
+                ck[(R + 1) * WAVE] = (uint32_t)S.rby;
+            }
+        }
+        const uint32_t t0 = 16u * tb;
+#ifndef SWMI_NO_ASM
+        if (t0 + 15u < n) {
+            // lane 0 stays inside the reference for all 16 steps: nobody has to be masked (a lane that has not started
+            // yet computes zeros from its zero operands, lanes without rows compute values nobody reads)
+            SweepStep4Asm<R>::run(S.h, S.g, S.hp, S.q, S.rbx, S.rby, w.x, w.y, one, gm, S.lmax);
+            SweepStep4Asm<R>::run(S.h, S.g, S.hp, S.q, S.rbx, S.rby, w.y, w.z, one, gm, S.lmax);
+            SweepStep4Asm<R>::run(S.h, S.g, S.hp, S.q, S.rbx, S.rby, w.z, w.w, one, gm, S.lmax);
+            SweepStep4Asm<R>::run(S.h, S.g, S.hp, S.q, S.rbx, S.rby, w.w, wnext.x, one, gm, S.lmax);
+        } else
+#endif
+        {
+#pragma unroll
+            for (uint32_t s = 0; s < 16; ++s) {
+                const uint32_t s1 = s + 1u;
+                const uint32_t wf = s1 < 4 ? w.x : s1 < 8 ? w.y : s1 < 12 ? w.z : s1 < 16 ? w.w : wnext.x;
+                const uint32_t code = (wf >> (8u * (s1 & 3u))) & 0xFFu;
+                const bool in_range = (t0 + s - lane_eff) < n;
+                if (s & 1u) sweep_step_ref<R>(S.g, S.h, S.hp, S.q, S.rby, S.rbx, code, gm, S.lmax, in_range);
+                else        sweep_step_ref<R>(S.h, S.g, S.hp, S.q, S.rbx, S.rby, code, gm, S.lmax, in_range);
+            }
+        }
+    }
+    {
+        const uint32_t gl = (nblk - 1u + (col0 >> 4)) / SWMI_CK_BLOCKS;
+        if (gl >= g_lo) close_window(gl);
+    }
+    if (lane != 0) return;
+    PairOut *o = &A.out[pd.out_id];
+    if (COLS) {
+        // combine the chunks: maximum by atomicMax (the record was zeroed by sw_sweep_winmax_kernel, one launch earlier),
+        // the last chunk to finish completes the record
+        if (pair_max > 0) atomicMax(&o->score, pair_max);
+        __threadfence();
+        const unsigned long long done = atomicAdd((unsigned long long *)&o->n_cells, 1ull);
+        if (done + 1ull == (unsigned long long)(pd.pad & ~SWMI_PAD_COLS)) {
+            __threadfence();
+            const int best = __hip_atomic_load(&o->score, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (best <= 0) { o->flags = SWMI_F_DEGENERATE; o->n_cells = (uint64_t)m * n_full; }
+            else           { o->flags = 0u; o->n_cells = 0; }
+        }
+        return;
+    }
+    PairOut v;                 // the cells holding the maximum are listed by the traceback kernel (n_cells follows there)
+    if (pair_max <= 0) { v.score = 0; v.flags = SWMI_F_DEGENERATE; v.n_cells = (uint64_t)m * n_full; }
+    else               { v.score = pair_max; v.flags = 0u; v.n_cells = 0; }
+    *o = v;
+}
+
+template <bool COLS>
+__device__ __forceinline__ void sweep_fast_dispatch(const FillArgs &A, const PairDesc pd, uint32_t lane, uint32_t m, const ColItem ci) {
+    const uint32_t R = swmi_rows_per_lane(m);
+    if (R == 1)      sweep_fast<1, COLS>(A, pd, lane, ci);
+    else if (R == 2) sweep_fast<2, COLS>(A, pd, lane, ci);
+    else if (R == 3) sweep_fast<3, COLS>(A, pd, lane, ci);
+    else             sweep_fast<4, COLS>(A, pd, lane, ci);
+}
+
 template <bool ACGT, bool STRICT, int MODE>
 __device__ __forceinline__ void fill_dispatch(const FillArgs &A, const PairDesc pd, uint32_t lane, uint32_t m) {
     const uint32_t R = swmi_rows_per_lane(m);
@@ -577,6 +751,15 @@ __device__ __forceinline__ void fill_entry(const FillArgs &A) {
     // profile lookup needs both sequences pure ACGT and scores that fit a signed byte
     const bool acgt = rd.acgt && qd.acgt &&
                       SWMI_SCORES_FIT(A);
+    if (MODE == SWMI_MODE_WINMAX && qd.len <= WAVE * SWMI_RMAX && (pd.pad & SWMI_PAD_COLS)) {
+        // swept chunk by chunk (sw_sweep_winmax_cols_kernel, next launch): start the record its chunks complete by atomics
+        if (lane == 0) { PairOut z; z.score = 0; z.flags = 0u; z.n_cells = 0; A.out[pd.out_id] = z; }
+        return;
+    }
+    if (MODE == SWMI_MODE_WINMAX && acgt && qd.len <= WAVE * SWMI_RMAX && A.gap <= 0) {
+        sweep_fast_dispatch<false>(A, pd, lane, qd.len, ColItem{0u, 0u, 0u, 0u});
+        return;
+    }
     if (MODE == SWMI_MODE_SCORE || MODE == SWMI_MODE_WINMAX) {   // scores do not depend on the tie order
         if (acgt) fill_dispatch<true, false, MODE>(A, pd, lane, qd.len);
         else      fill_dispatch<false, false, MODE>(A, pd, lane, qd.len);
@@ -613,6 +796,19 @@ sw_sweep_winmax_strips_kernel(const FillArgs A) {
                       SWMI_SCORES_FIT(A);
     if (acgt) fill_pair<SWMI_RMAX, true, false, true, SWMI_MODE_WINMAX, true>(A, pd, lane, it.y);
     else      fill_pair<SWMI_RMAX, false, false, true, SWMI_MODE_WINMAX, true>(A, pd, lane, it.y);
+}
+
+// mode 1, few pairs with long references: one wavefront per COLUMN CHUNK of a pair (swmi_device.h: ColItem).  The
+// chunks of a pair are independent -- each re-derives its left context from a halo no positive-score path can span --
+// so a 128 kbp reference against one read is swept by dozens of wavefronts at once instead of one 128 k-step chain.
+extern "C" __global__ void __launch_bounds__(WAVE * FILL_WAVES)
+sw_sweep_winmax_cols_kernel(const FillArgs A) {
+    const uint32_t item = blockIdx.x * FILL_WAVES + (threadIdx.x >> 6);
+    if (item >= A.n_col_items) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    const ColItem ci = A.col_items[item];
+    const PairDesc pd = A.pairs[ci.pair];
+    sweep_fast_dispatch<true>(A, pd, lane, A.reads[pd.read_id].len, ci);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1363,6 +1559,8 @@ extern "C" hipError_t swmi_launch_fill(const FillArgs *a, hipStream_t st) {
         hipLaunchKernelGGL(sw_sweep_winmax_kernel, grid, block, 0, st, *a);
         if (a->skip_multi && a->n_strip_items)
             hipLaunchKernelGGL(sw_sweep_winmax_strips_kernel, dim3((a->n_strip_items + FILL_WAVES - 1) / FILL_WAVES), block, 0, st, *a);
+        if (a->n_col_items)
+            hipLaunchKernelGGL(sw_sweep_winmax_cols_kernel, dim3((a->n_col_items + FILL_WAVES - 1) / FILL_WAVES), block, 0, st, *a);
     }
     else                   hipLaunchKernelGGL(sw_fill_score_kernel, grid, block, 0, st, *a);
     return hipGetLastError();

@@ -22,38 +22,73 @@ def shard_references(refs, rank, world):
     return refs[lo:hi], lo
 
 
+def _decode(g, cap):
+    """rows {local max, uncapped count, ids...} of every rank -> (global max, winners or None when a winning rank has
+    more ids than fit the fixed payload, the largest such count)"""
+    gbest = int(g[:, 0].max())
+    winners, need = [], 0
+    for row in g:
+        if int(row[0]) == gbest:
+            cnt = int(row[1])
+            need = max(need, cnt)
+            winners.extend(int(x) for x in row[2:2 + min(cnt, cap)])
+    return gbest, (sorted(winners) if need <= cap else None), need
+
+
+def _gather_all_winners(mine, is_winner, need, device, group):
+    """second exchange, only when some rank holds more tied winners than the fixed payload carries (duplicated
+    references, or a shard where nothing scores: `int max = 0` makes every total-0 reference a winner,
+    Distribution.java:573,600-613): every rank contributes `need` slots."""
+    import numpy as np
+    world = dist.get_world_size(group)
+    pay = np.full(need + 1, -1, dtype=np.int64)
+    if is_winner:
+        pay[0] = mine.size
+        pay[1:1 + mine.size] = mine
+    else:
+        pay[0] = 0
+    payload = torch.from_numpy(pay)
+    if device is not None:
+        payload = payload.to(device)
+    gathered = [torch.empty_like(payload) for _ in range(world)]
+    dist.all_gather(gathered, payload, group=group)
+    out = []
+    for row in torch.stack(gathered).cpu().numpy():
+        out.extend(int(x) for x in row[1:1 + int(row[0])])
+    return sorted(out)
+
+
 def global_max_with_ties(local_totals, global_ids, device=None, group=None, cap=64):
-    """Control-path reduce across ranks (Distribution.java:600-613): returns (max_total, sorted ids of every
+    """Control-path reduce across ranks (Distribution.java:600-613): returns (max_total, sorted ids of EVERY
     reference whose total equals it).  local_totals/global_ids: equal-length int sequences (or numpy arrays) of
     this rank's shard.  `max` starts at 0 like the reference's (`int max = 0`, :573), so totals below 0 never win.
 
-    ONE collective: every rank contributes {its local max, the ids reaching it} (cap+2 int64 = 528 B) to an
-    all-gather; the global max and its references follow locally and identically on every rank.  (A separate
-    all-reduce(max) first would cost a second latency-bound round trip for the same information.)"""
+    ONE collective in the usual case: every rank contributes {its local max, how many ids reach it, the first `cap` of
+    them} (cap+2 int64 = 528 B) to an all-gather; the global max and its references follow locally and identically on
+    every rank.  Only when a winning rank holds more than `cap` ids does a second all-gather, sized by the largest
+    count, fetch the complete lists -- nothing is ever cut."""
     import numpy as np
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     t = np.asarray(local_totals, dtype=np.int64)
     ids = np.asarray(global_ids, dtype=np.int64)
     local_best = max(int(t.max()), 0) if t.size else 0
-    mine = ids[t == local_best][:cap] if t.size else ids[:0]
+    mine = ids[t == local_best] if t.size else ids[:0]
     if world == 1:
         return local_best, sorted(int(x) for x in mine)
     pay = np.full(cap + 2, -1, dtype=np.int64)
     pay[0] = local_best
     pay[1] = mine.size
-    pay[2:2 + mine.size] = mine
+    pay[2:2 + min(mine.size, cap)] = mine[:cap]
     payload = torch.from_numpy(pay)
     if device is not None:
         payload = payload.to(device)
     gathered = [torch.empty_like(payload) for _ in range(world)]
     dist.all_gather(gathered, payload, group=group)
     g = torch.stack(gathered).cpu().numpy()
-    gbest = int(g[:, 0].max())
-    winners = []
-    for row in g:
-        if int(row[0]) == gbest:
-            winners.extend(int(x) for x in row[2:2 + int(row[1])])
-    return gbest, sorted(winners)
+    gbest, winners, need = _decode(g, cap)
+    if winners is None:
+        winners = _gather_all_winners(mine, local_best == gbest, need, device, group)
+    return gbest, winners
 
 
 class MaxReducer:
@@ -63,7 +98,9 @@ class MaxReducer:
 
     submit() only enqueues the exchange and returns a ticket; collect(ticket) waits for it and decodes.  A driver
     that streams shards (bench.py) submits step k and collects step k-1, so the collective's latency hides behind
-    the next shard's kernels (the library runs on its own HIP stream).  `depth` exchanges may be in flight."""
+    the next shard's kernels (the library runs on its own HIP stream).  `depth` exchanges may be in flight.
+    More than `cap` tied winners on a winning rank: collect() runs the second, exactly-sized exchange (every rank sees
+    the same counts, so every rank enters it)."""
 
     def __init__(self, device, cap=64, group=None, depth=2, always_exchange=False):
         self.cap, self.group, self.device, self.depth = cap, group, device, depth
@@ -81,7 +118,7 @@ class MaxReducer:
                 "d_pay": torch.empty(cap + 2, dtype=torch.int64, device=device),
                 "d_all": torch.empty(self.world * (cap + 2), dtype=torch.int64, device=device),
                 "h_all": h_all, "all_np": h_all.numpy().reshape(self.world, cap + 2),
-                "event": torch.cuda.Event() if on_gpu else None, "local": None,
+                "event": torch.cuda.Event() if on_gpu else None, "local": None, "mine": None,
             })
         self.n_submitted = 0
 
@@ -89,16 +126,18 @@ class MaxReducer:
         import numpy as np
         t = np.asarray(local_totals)
         local_best = max(int(t.max()), 0) if t.size else 0
-        mine = np.asarray(global_ids)[t == local_best][:self.cap] if t.size else np.empty(0, dtype=np.int64)
+        mine = np.asarray(global_ids, dtype=np.int64)[t == local_best] if t.size else np.empty(0, dtype=np.int64)
         ticket = self.n_submitted
         self.n_submitted += 1
         sl = self.slots[ticket % self.depth]
         sl["local"] = (local_best, sorted(int(x) for x in mine))
+        sl["mine"] = mine
         if not self.exchange:
             return ticket
         sl["pay_np"][0] = local_best
         sl["pay_np"][1] = mine.size
-        sl["pay_np"][2:2 + mine.size] = mine
+        k = min(mine.size, self.cap)
+        sl["pay_np"][2:2 + k] = mine[:k]
         sl["d_pay"].copy_(sl["h_pay"], non_blocking=True)
         if self.flat_gather:
             dist.all_gather_into_tensor(sl["d_all"], sl["d_pay"], group=self.group)
@@ -117,13 +156,11 @@ class MaxReducer:
             return sl["local"]
         if sl["event"] is not None:
             sl["event"].synchronize()
-        g = sl["all_np"]
-        gbest = int(g[:, 0].max())
-        winners = []
-        for row in g:
-            if int(row[0]) == gbest:
-                winners.extend(int(x) for x in row[2:2 + int(row[1])])
-        return gbest, sorted(winners)
+        gbest, winners, need = _decode(sl["all_np"], self.cap)
+        if winners is None:
+            winners = _gather_all_winners(sl["mine"], sl["local"][0] == gbest, need,
+                                          self.device if self.on_gpu else None, self.group)
+        return gbest, winners
 
     def __call__(self, local_totals, global_ids):
         return self.collect(self.submit(local_totals, global_ids))

@@ -1,0 +1,122 @@
+"""The drop-in boundary beyond symbol checks: the JNI shim's call sequence as a plain C99 program (the build image has
+no JDK, so bindings/jni/swmi_jni.c itself cannot be compiled; its logic lives in bindings/jni/swmi_shim.c, which is),
+re-entrancy of the C ABI (MapRef.call runs on every executor thread, src/sw/Distribution.java:32,403), and the
+error / fallback paths of the runtime."""
+import os
+import random
+import subprocess
+import threading
+
+import pytest
+
+import sparksmithwaterman_amd as sw
+from sparksmithwaterman_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _build_shim(tmp_path):
+    exe = tmp_path / "shim_kat"
+    lib = os.path.join(ROOT, "sparksmithwaterman_amd", "lib")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic",
+                           "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "bindings", "jni"),
+                           os.path.join(ROOT, "tests", "c", "shim_kat.c"), os.path.join(ROOT, "bindings", "jni", "swmi_shim.c"),
+                           "-L", lib, "-lswmi", "-Wl,-rpath," + lib, "-o", str(exe)])
+    return exe
+
+
+def test_shim_sequence_is_c99_clean_and_fails_loudly_without_gpu(tmp_path):
+    import torch
+    exe = _build_shim(tmp_path)
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the gpu test")
+    p = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert p.returncode == 3 and "no CPU fallback" in p.stdout
+
+
+def test_jni_translation_unit_includes_what_it_uses():
+    src = open(os.path.join(ROOT, "bindings", "jni", "swmi_jni.c")).read()
+    assert "#include <stdio.h>" in src                      # snprintf (it had never met a compiler)
+    assert "GetDirectBufferCapacity" in src and "GetArrayLength" in src
+
+
+@pytest.mark.gpu
+def test_shim_sequence_matches_kat3(tmp_path, kats):
+    exe = _build_shim(tmp_path)
+    for arg, name in (("serial", "KAT-3-serial"), ("strict", "KAT-3-strict")):
+        k = next(x for x in kats if x["name"] == name)
+        out = subprocess.run([str(exe), arg], capture_output=True, text=True, check=True).stdout.split()
+        want = k.get("map_ref_sorted", k["alignments"])
+        assert out[0] == str(k["score"]) and out[1] == str(len(want))
+        assert out[2:] == ["%d:%s/%s" % (b, r, q) for b, r, q in want]
+
+
+@pytest.mark.gpu
+def test_two_contexts_on_two_threads():
+    """Two contexts, two host threads, different batches running at the same time (ctypes drops the GIL in the calls):
+    each thread gets its own results, identical to what the same batch gives alone."""
+    from oracle import sw_oracle as orc
+    jobs = [synth.config_1k(n_refs=300, ref_len=700, read_len=150, seed=11),
+            synth.config_ncbi(250, read_len=100, seed=12)]
+    want = []
+    for refs, reads in jobs:
+        r = orc.bench(refs, reads, nthreads=8, per_pair=True)
+        want.append((r["pair_score"], r["pair_naln"]))
+    errors, got = [], [None, None]
+
+    def worker(k):
+        try:
+            ctx = sw.Context(0)
+            refs, reads = jobs[k]
+            b = ctx.upload(refs, reads)
+            for _ in range(6):
+                b.run()
+                sc, na = b.pair_results()
+                assert list(sc) == want[k][0] and [int(x) for x in na] == want[k][1]
+            # a third, small batch per thread through the one-shot mirror class
+            s, a = sw.SmithWaterman.OptAlignments(ctx).call([refs[0], reads[0]])
+            assert (s, a) == orc.opt_alignments((refs[0], reads[0]))
+            got[k] = True
+            b.free()
+            ctx.close()
+        except BaseException as e:      # noqa: BLE001 - reported by the main thread
+            errors.append((k, repr(e)))
+
+    ts = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(300)
+    assert not errors, errors
+    assert got == [True, True]
+
+
+@pytest.mark.gpu
+def test_strip_pipeline_give_up_falls_back_to_one_wave_sweep():
+    """Long reads are swept one wavefront per strip, each strip waiting for the one above it.  With the items dispatched
+    consumer-first and a spin budget of one poll the consumers give up; the runtime must then re-run the chunk with the
+    one-wavefront sweep and still return the oracle's results (the batch used to fail with SWMI_ERR_HIP)."""
+    from oracle import sw_oracle as orc
+    rng = random.Random(5)
+    refs = ["".join(rng.choice("ACGT") for _ in range(n)) for n in (1500, 2100)]
+    reads = [refs[0][100:900], refs[1][50:600], refs[0][300:450]]
+    ctx = sw.Context(0)
+    ctx.set_option("mode", 1)
+    ctx.set_option("debug_reverse_strips", 1)
+    ctx.set_option("debug_strip_spins", 1)
+    b = ctx.upload(refs, reads).run()
+    assert b.timing().strip_fallbacks >= 1
+    for r, ref in enumerate(refs):
+        for q, read in enumerate(reads):
+            es, ea = orc.opt_alignments((ref, read))
+            assert b.score(r * len(reads) + q) == es
+            assert b.alignments(r * len(reads) + q) == ea
+    b.free()
+    # the knobs off again: the pipeline itself, no fallback
+    ctx.set_option("debug_reverse_strips", 0)
+    ctx.set_option("debug_strip_spins", 0)
+    b = ctx.upload(refs, reads).run()
+    assert b.timing().strip_fallbacks == 0
+    assert b.score(0) == orc.opt_alignments((refs[0], reads[0]))[0]
+    b.free()
+    ctx.close()

@@ -38,6 +38,19 @@ def _worker(rank, world, port, q):
         assert False, "a ticket that left the ring must be refused"
     except ValueError:
         pass
+    # more tied winners than the fixed payload carries: duplicated references ...
+    many = list(range(1000 * rank, 1000 * rank + 150))
+    full = swd.global_max_with_ties([42] * 150, many)
+    assert full == (42, sorted(list(range(0, 150)) + list(range(1000, 1150))))
+    assert red([42] * 150, many) == full
+    # ... only one rank over the cap, the other one below the maximum ...
+    if rank == 0:
+        assert red([9] * 100, many[:100]) == (9, many[:100])
+    else:
+        assert red([3, 8], [1000, 1001]) == (9, list(range(0, 100)))
+    # ... and the all-zero case: `int max = 0` makes EVERY reference of a shard where nothing scores a winner
+    zero = swd.global_max_with_ties([0] * 70, list(range(100 * rank, 100 * rank + 70)))
+    assert zero == (0, list(range(0, 70)) + list(range(100, 170)))
     q.put((rank, best, winners, topk, neg))
     dist.destroy_process_group()
 

@@ -19,8 +19,8 @@ READ_80 = "AATTTTAGTCTCTCCCTACCCTTTTGGACAGAGCTTCCTGTCCTCTCATTTCACAGGTTATGCAACAGA
 READ_20 = "ACTGACTGACTGACTGACTG"   # EngineerData.java:29
 
 
-@pytest.fixture(scope="module", params=[(1, 1), (2, 1), (0, 1), (1, 0)],
-                ids=["mode1-winmax", "mode2-events", "mode0-field", "mode1-d2h-copy"])
+@pytest.fixture(scope="module", params=[(1, 1), (2, 1), (0, 1), (1, 0), (-1, 1)],
+                ids=["mode1-winmax", "mode2-events", "mode0-field", "mode1-d2h-copy", "automatic"])
 def ctx(request):
     """Every kernel pipeline (include/swmi.h, swmi_set_option "mode"), results written straight to pinned host
     memory or fetched by a copy."""
@@ -320,4 +320,65 @@ def test_run_async_matches_run(ctx):
         assert [(b.score(k), b.alignments(k)) for k in range(len(refs))] == want
     with pytest.raises(sw.SwmiError):
         b.wait()                               # nothing in flight
+    b.free()
+
+
+def test_column_chunks_of_long_references(ctx):
+    """Few pairs, long references: the mode-1 sweep of a pair is cut into column chunks, one wavefront each, every chunk
+    re-deriving its left context from a halo no positive-score path can span (swmi_device.h: ColItem).  Checked against
+    the oracle in full -- scores, every tied maximum, every alignment -- for forced chunk counts and the automatic one,
+    random and periodic references (EngineerData.java:118: REF repeated, one tied maximum per period)."""
+    rng = random.Random(42)
+    rnd = ["".join(rng.choice("ACGT") for _ in range(n)) for n in (9000, 20011, 4097)]
+    reads = [rnd[0][4000:4150], rnd[1][10:90], READ_80, rnd[1][19000:19250]]
+    refs = rnd + [REF * 130, "T" * 5000 + reads[0] + "T" * 3000 + reads[0][:120] + "T" * 900]
+    for chunks in (0, 2, 7, 64, 1):
+        ctx.set_option("col_chunks", chunks)
+        try:
+            b = ctx.upload(refs, reads).run()
+            if chunks > 1 and b.pipeline_mode() == 1:
+                assert b.timing().col_chunks >= 2 * len(reads)
+            if chunks == 1:
+                assert b.timing().col_chunks == 0
+            b.free()
+            check_batch(ctx, refs, reads)
+            check_batch(ctx, refs[:2], reads[:2], scores=(2, -1, -3), tie=1)
+        finally:
+            ctx.set_option("col_chunks", 0)
+
+
+def test_config3_shape_many_reads_totals_winners_topk(ctx):
+    """configs[3] shape on one GPU: many reads x NCBI-shaped references -> per-reference totals (MapRef, Distribution.java:
+    403-436) -> the driver's max-with-ties reduce (:600-613) and the top-K the multi-GPU path exchanges.  Every pair's
+    score and alignment count against the oracle, full match-site lists on a sample of references."""
+    import numpy as np
+    from sparksmithwaterman_amd import distributed as swd
+    refs, reads = synth.config_multi_read(500, 64, read_len=150, seed=3)
+    b = ctx.upload(refs, reads).run()
+    ob = orc.bench(refs, reads, nthreads=16, per_pair=True)
+    sc, na = b.pair_results()
+    assert [int(x) for x in sc] == ob["pair_score"]
+    assert [int(x) for x in na] == ob["pair_naln"]
+    totals = b.ref_totals()
+    want_tot = np.asarray(ob["pair_score"], dtype=np.int64).reshape(len(refs), len(reads)).sum(axis=1)
+    assert [int(x) for x in totals] == [int(x) for x in want_tot]
+    # the driver's reduce: running maximum with ties, over MapRef results
+    red = sw.Distribution.ReduceMax()
+    for r in range(len(refs)):
+        red.add(int(totals[r]), ([">gi|ref%d" % r, refs[r]], None))
+    mx, opt = red.result()
+    assert mx == int(want_tot.max())
+    assert sorted(int(v[0][0][7:]) for v in opt) == [int(r) for r in np.flatnonzero(want_tot == want_tot.max())]
+    # what the sharded path computes: two shards reduced as two ranks would, and the top-K merge
+    lo0, hi0 = swd.shard_bounds(len(refs), 0, 2)
+    assert swd.global_max_with_ties(totals[lo0:hi0], range(lo0, hi0))[0] <= mx
+    topk = swd.global_top_k(totals, range(len(refs)), 8)
+    order = sorted(range(len(refs)), key=lambda r: (-int(want_tot[r]), r))[:8]
+    assert topk == [(int(want_tot[r]), r) for r in order]
+    # full MapRef output (match sites stably sorted by begin) on the winners and a sample
+    rng = random.Random(9)
+    for r in set(order[:3] + rng.sample(range(len(refs)), 5)):
+        t, (_, sites) = orc.map_ref((">gi|r", refs[r]), reads)
+        assert int(totals[r]) == t
+        assert b.ref_match_sites(r) == sites
     b.free()

@@ -1,0 +1,156 @@
+#!/usr/bin/env python3
+"""Generates sparksmithwaterman_amd/csrc/swmi_step_gen.inc: the anti-diagonal steps of the mode-1 score sweep
+(sw_sweep_winmax_kernel, fast symbols, single strip) as a hand-scheduled gfx950 instruction stream, FOUR steps per
+asm statement (hipcc pads every boundary between two asm statements with an s_nop of its own) -- per step the lane's
+R cells, both neighbour exchanges, the reference feed and the window maximum.
+
+State of a lane (swmi_kernels.hip, SweepFast): H of its R rows ping-pongs between two register sets (hin = the
+previous step's, hout = the one before, overwritten here); hp[k] = max(H[k] + gap, 0) is kept beside it, in place.
+With gap <= 0 the recurrence of SmithWaterman.java:223-249
+    H = max(0, W + gap, N + gap, NW + s)        becomes        H = max3(NW + s, hp(N), hp(W))
+because hp >= 0 already carries the clamp: 3 VALU per cell instead of 4,
+    v_dot8_i32_i4  a, q, rb, diag        a = NW + s(ref,read)   (one-hot symbol . row profile, + diagonal)
+    v_max3_i32     H, a, hp_up, hp_left
+    v_sub_u32      hp, H, |gap| clamp    unsigned saturating: max(H - |gap|, 0)
+Row 0 takes its neighbours from lane l-1 through the DPP network INSIDE the arithmetic (no separate v_mov_dpp):
+    v_dot8_i32_i4  s0, q0, rb, 0
+    v_add_u32_dpp  a0, hout[R-1], s0  wave_shr:1 bound_ctrl   NW = lane l-1's bottom row two steps ago (lane 0: 0)
+    v_max_i32_dpp  x,  hp[R-1],  hp0  wave_shr:1 bound_ctrl   max(hp(N), hp(W))          (lane 0: N = 0)
+    v_max_i32      H0, a0, x
+The one-hot reference symbol of the NEXT step is prepared here (v_lshlrev_b32_sdwa feed for lane 0 + one v_mov_b32_dpp
+shift), so a step never starts with a dependent pair.  The per-lane window maximum takes v_max3 on 2 values at a time:
+an even step leaves its last row for the odd one when R is odd.
+
+Hazards the script enforces by construction (it simulates the previous step's tail in front of each stream and
+pads with s_nop where an instruction order cannot avoid it):
+  * v_dot* result read by another VALU opcode: 3 wait states;
+  * a VGPR written by a VALU and read through DPP (or overwritten by a DPP mov): 2 wait states.
+"""
+import os
+import sys
+
+DOT_WAIT = 3
+DPP_WAIT = 2
+
+
+class Ins:
+    def __init__(self, text, wr=(), rd=(), dot=(), dpp_rd=(), dpp_wr=()):
+        self.text = text
+        self.wr, self.rd, self.dot, self.dpp_rd, self.dpp_wr = tuple(wr), tuple(rd), tuple(dot), tuple(dpp_rd), tuple(dpp_wr)
+        self.states = 1
+
+
+def stream(R, odd, feed_byte):
+    """instruction list of one step; register names are asm operand names.  Even steps read h / write g and consume
+    rbx / prepare rby; odd steps the other way round."""
+    H, G = ("g", "h") if odd else ("h", "g")
+    RB, RBN = ("rby", "rbx") if odd else ("rbx", "rby")
+    WF = "wf1" if feed_byte == 0 else "wf0"          # the last step of a group of four is fed from the next dword
+    hin = lambda k: f"%[{H}{k}]"
+    hout = lambda k: f"%[{G}{k}]"
+    hp = lambda k: f"%[p{k}]"
+    dpp = "wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0"
+    ins = []
+    ins.append(Ins(f"v_dot8_i32_i4 %[s0], %[q0], %[{RB}], 0", wr=["s0"], dot=["s0"], rd=["q0", RB]))
+    for k in range(1, R):
+        ins.append(Ins(f"v_dot8_i32_i4 %[a{k}], %[q{k}], %[{RB}], {hin(k-1)}", wr=[f"a{k}"], dot=[f"a{k}"], rd=[f"q{k}", RB, f"{H}{k-1}"]))
+    ins.append(Ins(f"v_lshlrev_b32_sdwa %[{RBN}], %[{WF}], %[one] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_{feed_byte} src1_sel:DWORD",
+                   wr=[RBN], rd=[WF, "one"]))
+    ins.append(Ins(f"v_max_i32_dpp %[x], {hp(R-1)}, {hp(0)} {dpp}", wr=["x"], rd=["p0"], dpp_rd=[f"p{R-1}"]))
+    ins.append(Ins(f"v_add_u32_dpp %[a0], {hout(R-1)}, %[s0] {dpp}", wr=["a0"], rd=["s0"], dpp_rd=[f"{G}{R-1}"]))
+    ins.append(Ins(f"v_mov_b32_dpp %[{RBN}], %[{RB}] wave_shr:1 row_mask:0xf bank_mask:0xf", dpp_rd=[RB], dpp_wr=[RBN], wr=[RBN]))
+    ins.append(Ins(f"v_max_i32_e32 {hout(0)}, %[a0], %[x]", wr=[f"{G}0"], rd=["a0", "x"]))
+    ins.append(Ins(f"v_sub_u32_e64 {hp(0)}, {hout(0)}, %[gm] clamp", wr=["p0"], rd=[f"{G}0"]))
+    for k in range(1, R):
+        ins.append(Ins(f"v_max3_i32 {hout(k)}, %[a{k}], {hp(k-1)}, {hp(k)}", wr=[f"{G}{k}"], rd=[f"a{k}", f"p{k-1}", f"p{k}"]))
+        ins.append(Ins(f"v_sub_u32_e64 {hp(k)}, {hout(k)}, %[gm] clamp", wr=[f"p{k}"], rd=[f"{G}{k}"]))
+    # window maximum: even steps consume 2*floor(R/2) of their values, odd steps the leftover row of the even step + their own
+    vals = [hout(k) for k in range(R)]
+    if not odd:
+        vals = vals[:2 * (R // 2)]
+    elif R % 2:
+        vals = [hin(R - 1)] + vals
+    for j in range(0, len(vals), 2):
+        ins.append(Ins(f"v_max3_i32 %[lm], %[lm], {vals[j]}, {vals[j+1]}", wr=["lm"], rd=["lm"]))
+    return ins
+
+
+def pad_hazards(prev_tail, body):
+    """inserts s_nop into `body` so that every hazard holds, given the instructions that ran just before it"""
+    out = list(prev_tail)
+    base = len(out)
+    for i in body:
+        need = 0
+        def states_since(pos):
+            return sum(o.states for o in out[pos + 1:])
+        for pos in range(len(out) - 1, -1, -1):
+            o = out[pos]
+            if states_since(pos) >= max(DOT_WAIT, DPP_WAIT):
+                break
+            if not i.dot:
+                for r in o.dot:
+                    if r in i.rd or r in i.dpp_rd:
+                        need = max(need, DOT_WAIT - states_since(pos))
+            for r in o.wr:
+                if r in i.dpp_rd or r in i.dpp_wr:
+                    need = max(need, DPP_WAIT - states_since(pos))
+        if need > 0:
+            nop = Ins(f"s_nop {need - 1}")
+            nop.states = need
+            out.append(nop)
+        out.append(i)
+    return out[base:]
+
+
+def emit(R):
+    """four consecutive steps (phases 0..3 of a 16-step block) as ONE asm statement: the compiler pads every boundary
+    between two asm statements with an s_nop of its own"""
+    group = []
+    for ph in range(4):
+        group += stream(R, ph & 1, (ph + 1) & 3)
+    prev = stream(R, 1, 0)                             # the step before the group is phase 3 of the previous one
+    body = pad_hazards(prev[-4:], group)
+    n_nop = sum(1 for i in body if i.text.startswith("s_nop"))
+    n_valu = len(body) - n_nop
+    L = []
+    L.append(f"// R={R}: four steps, {n_valu} VALU, {n_nop} s_nop  ({n_valu / 4:.2f} VALU per step, {n_valu / 4 / R:.2f} per cell)")
+    L.append(f"template <> struct SweepStep4Asm<{R}> {{")
+    L.append(f"    static __device__ __forceinline__ void run(int (&h)[{R}], int (&g)[{R}], int (&hp)[{R}], const int (&q)[{R}],")
+    L.append(f"                                               int &rbx, int &rby, const uint32_t wf0, const uint32_t wf1,")
+    L.append(f"                                               const int one, const uint32_t gm, int &lm) {{")
+    L.append("        int s0, a0, x" + "".join(f", a{k}" for k in range(1, R)) + ";")
+    L.append("        asm volatile(")
+    for i in body:
+        L.append(f'            "{i.text}\\n\\t"')
+    outs = [f'[h{k}] "+v"(h[{k}])' for k in range(R)] + [f'[g{k}] "+v"(g[{k}])' for k in range(R)]
+    outs += [f'[p{k}] "+v"(hp[{k}])' for k in range(R)]
+    outs += ['[rbx] "+v"(rbx)', '[rby] "+v"(rby)', '[lm] "+v"(lm)', '[s0] "=&v"(s0)', '[a0] "=&v"(a0)', '[x] "=&v"(x)']
+    outs += [f'[a{k}] "=&v"(a{k})' for k in range(1, R)]
+    ins_ = [f'[q{k}] "v"(q[{k}])' for k in range(R)]
+    ins_ += ['[wf0] "v"(wf0)', '[wf1] "v"(wf1)', '[one] "v"(one)', '[gm] "s"(gm)']
+    L.append("            : " + ", ".join(outs))
+    L.append("            : " + ", ".join(ins_))
+    L.append("            : );")
+    L.append("    }")
+    L.append("};")
+    return "\n".join(L), n_valu, n_nop
+
+
+def main():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, "sparksmithwaterman_amd", "csrc", "swmi_step_gen.inc")
+    parts = ["// GENERATED by tools/gen_step.py -- do not edit; re-run the script instead.",
+             "// Four anti-diagonal steps of the mode-1 score sweep per specialisation (see the script's docstring).",
+             "template <int R> struct SweepStep4Asm;", ""]
+    for R in (1, 2, 3, 4):
+        text, nv, nn = emit(R)
+        parts.append(text)
+        parts.append("")
+        print(f"R={R}: {(nv + nn) / 4:.2f} instructions per step ({(nv + nn) / 4 / R:.2f} per cell), {nn} s_nop per 4 steps")
+    with open(path, "w") as f:
+        f.write("\n".join(parts))
+    print("wrote", path)
+
+
+if __name__ == "__main__":
+    sys.exit(main())
