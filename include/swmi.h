@@ -89,8 +89,13 @@ void        swmi_default_params(swmi_params *p);
  *   0            the sweep writes the whole 2-bit direction field to HBM and the traceback reads it
  *                (cheaper when most pairs have many tied maxima).  Batches with pairs longer than about
  *                16 k bases (m + n) run as mode 1/2: mode 0's traceback tiles leave too little LDS for them.
- *  -1            automatic (the default): mode 1, unless a sample of the batch's pairs (aligned once, on the first
- *                run of the batch) shows many tied maxima per pair -- periodic references -- where mode 0 is faster.
+ *  -1            the same as 1 (kept for callers that passed "automatic").
+ * tb_split: grain of the mode-1 traceback.  0: one workgroup per pair (lists the maximum cells, then up to four waves walk
+ *                the alignments, the others re-sweep windows for them) -- best when pairs have one or a few alignments;
+ *                1: split -- one wavefront per checkpoint window lists cells, one wavefront per alignment walks; -1
+ *                (default): split for launches of fewer than 64 pairs and for batches in which a sample of the pairs
+ *                (aligned once, on the first run of a batch) averages >= auto_ties_x100 / 100 tied maxima per pair --
+ *                periodic references, the reference's own EngineerData sets.
  * Further knobs: spin_us (how long a run polls its stream before it blocks, default 2000); col_chunks (0 automatic,
  * 1 never, N > 1 force up to N column chunks per pair: a launch of few pairs with long references is swept by several
  * wavefronts per pair); debug_strip_spins / debug_reverse_strips (tests of the strip pipeline's give-up path). */

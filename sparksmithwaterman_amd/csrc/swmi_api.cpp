@@ -28,6 +28,7 @@
 
 extern "C" hipError_t swmi_launch_fill(const FillArgs *a, hipStream_t st);
 extern "C" hipError_t swmi_launch_traceback(const TraceArgs *a, hipStream_t st);
+extern "C" hipError_t swmi_launch_traceback_split(const TraceArgs *a, uint32_t n_windows, hipStream_t st);
 extern "C" hipError_t swmi_launch_encode(const uint8_t *raw, const uint64_t *raw_off, SeqDesc *desc, uint32_t *seqw,
                                          const uint8_t *lut, uint32_t n_seq, hipStream_t st);
 
@@ -115,6 +116,8 @@ struct swmi_ctx {
     int auto_mode = 1;                      // choose the pipeline per batch unless "mode" was set explicitly
     uint32_t auto_ties_x100 = 300;          // automatic mode: mode 0 when a sampled pair has this many tied maxima (x 1/100) on average
     uint32_t col_chunks = 0;                // test knob: force this many column chunks per pair (0 = automatic)
+    int tb_split = -1;                      // mode-1 traceback grain: -1 automatic, 0 one workgroup per pair, 1 one wavefront per window / alignment
+    bool cell_cap_set = false;              // cell_cap given by the caller (otherwise small launches get longer lists)
     // swmi_batch_run_async: one run in flight on the context's own host thread
     std::thread worker;
     std::mutex job_mu;
@@ -163,12 +166,14 @@ struct swmi_batch {
     DevBuf d_seqw, d_refs, d_reads, d_pairs, d_dir, d_seam, d_result, d_cells, d_cells_off, d_cells_cap, d_dbg, d_dbg2;
     DevBuf d_strip_items, d_progress;       // mode 1: strip-per-wavefront sweep of long reads
     DevBuf d_col_items;                     // mode 1: column chunks of single-strip pairs
+    DevBuf d_win_off, d_queue;              // split traceback: per-pair window offsets, walk-item queue
+    bool tb_split_used = false;             // the last run used the split traceback
     bool acgt_known = false;                // ref_desc/read_desc[].acgt fetched back from the device (set there by the encode kernel)
     PinnedBuf h_result;
     // per run
     swmi_params params{};
     bool has_run = false;
-    int auto_choice = -1;                   // pipeline chosen by the sampled pre-pass (automatic mode), -1: not decided yet
+    int auto_choice = -1;                   // sampled pre-pass of the automatic traceback grain: 0 tie-heavy, 1 not, -1 not decided yet
     swmi_params auto_params{};
     std::vector<Work> work;                 // schedule (pairs sorted by work), valid for work_mode
     int work_mode = -1;
@@ -187,6 +192,7 @@ struct swmi_batch {
         uint64_t dir_words = 0, seam_words = 0;
         uint32_t max_path = 0, max_read = 0;
         size_t n_strip_items = 0, n_col_items = 0;
+        uint64_t n_windows = 0;
         uint32_t col_chunks_opt = 0;
         bool reverse_strips = false;
     } prep;
@@ -295,6 +301,7 @@ extern "C" int swmi_set_option(swmi_ctx *ctx, const char *name, int64_t value) {
     if (!strcmp(name, "cell_cap")) {
         if (value < 1 || value > (1 << 20)) return fail(SWMI_ERR_INVALID, "cell_cap out of range");
         ctx->cell_cap = (uint32_t)value;
+        ctx->cell_cap_set = true;
     } else if (!strcmp(name, "max_workspace_bytes")) {
         if (value < (1 << 20)) return fail(SWMI_ERR_INVALID, "max_workspace_bytes too small");
         ctx->max_workspace_bytes = (uint64_t)value;
@@ -313,6 +320,9 @@ extern "C" int swmi_set_option(swmi_ctx *ctx, const char *name, int64_t value) {
         ctx->dbg_strip_spins = (uint32_t)value;
     } else if (!strcmp(name, "debug_reverse_strips")) {
         ctx->dbg_reverse_strips = value != 0;
+    } else if (!strcmp(name, "tb_split")) {
+        if (value < -1 || value > 1) return fail(SWMI_ERR_INVALID, "tb_split must be -1 (automatic), 0 or 1");
+        ctx->tb_split = (int)value;
     } else if (!strcmp(name, "col_chunks")) {
         if (value < 0 || value > 4096) return fail(SWMI_ERR_INVALID, "col_chunks out of range");
         ctx->col_chunks = (uint32_t)value;
@@ -394,7 +404,7 @@ extern "C" void swmi_batch_free(swmi_ctx *ctx, swmi_batch *b) {
     b->d_seqw.release(); b->d_refs.release(); b->d_reads.release(); b->d_pairs.release();
     b->d_dir.release(); b->d_seam.release(); b->d_result.release(); b->d_cells.release();
     b->d_cells_off.release(); b->d_cells_cap.release(); b->d_dbg.release(); b->d_dbg2.release();
-    b->d_strip_items.release(); b->d_progress.release(); b->d_col_items.release();
+    b->d_strip_items.release(); b->d_progress.release(); b->d_col_items.release(); b->d_win_off.release(); b->d_queue.release();
     b->h_result.release();
     delete b;
 }
@@ -478,6 +488,7 @@ struct RunState {
     uint32_t launches = 0;
     double enqueue_us = 0, wait_us = 0, copyout_us = 0;
     bool one_wave_sweep = false;            // the strip pipeline gave up once in this run: long reads are swept by one wavefront
+    bool tb_split = false;                  // mode 1: detect per window + walk per alignment instead of one workgroup per pair
 };
 
 // layout of the device result block: [ArenaHdr | PairOut x np | arena words ...]
@@ -524,6 +535,8 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
     uint64_t dir_words = 0, seam_words = 0;
     uint32_t max_path = 0, max_read = 0;
     size_t n_strip_items = 0, n_col_items = 0;
+    uint64_t n_windows = 0;
+    std::vector<uint32_t> win_off;           // split traceback: first window of every pair
     swmi_batch::Prep &pr = b->prep;
     const bool prepared = pr.valid && pr.lo == lo && pr.hi == hi && pr.work == (const void *)work.data() && pr.mode == b->eff_mode &&
                           memcmp(&pr.params, &b->params, sizeof(swmi_params)) == 0 && b->pairs_dev_ptr == b->d_pairs.p &&
@@ -531,7 +544,7 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
                           pr.reverse_strips == (ctx->dbg_reverse_strips != 0);
     if (prepared) {
         dir_words = pr.dir_words; seam_words = pr.seam_words; max_path = pr.max_path; max_read = pr.max_read;
-        n_strip_items = pr.n_strip_items; n_col_items = pr.n_col_items;
+        n_strip_items = pr.n_strip_items; n_col_items = pr.n_col_items; n_windows = pr.n_windows;
     } else {
     // Column chunks (swmi_device.h: ColItem): a launch of few pairs leaves most of the 1024 SIMDs idle while every pair is
     // one dependent chain of n + 63 steps.  A positive-score path spans at most m + match*m/|gap| columns (A <= m
@@ -548,6 +561,7 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
     }
     const uint64_t chunk_budget = ctx->col_chunks > 1 ? ctx->col_chunks : std::max<uint64_t>(1, 1024 / std::max<size_t>(np, 1));
     pd.resize(np);
+    if (b->eff_mode == 1) win_off.resize(np + 1);
     for (size_t k = 0; k < np; k++) {
         const Work &w = work[lo + k];
         PairDesc d{};
@@ -559,6 +573,12 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
         dir_words += w.dir_words;
         seam_words += w.seam_words;
         const uint32_t m_ = b->read_desc[d.read_id].len, n_ = b->ref_desc[d.ref_id].len;
+        if (b->eff_mode == 1) {
+            const uint64_t rps = 64ull * swmi_rows_per_lane(m_);
+            const uint64_t wb = ((uint64_t)n_ + 63u + 15u) / 16u;
+            win_off[k] = (uint32_t)std::min<uint64_t>(n_windows, 0xFFFFFFFFu);
+            n_windows += ((m_ + rps - 1) / rps) * ((wb + SWMI_CK_BLOCKS - 1u) / SWMI_CK_BLOCKS);
+        }
         if (b->eff_mode == 1 && m_ > 64u * SWMI_RMAX && strip_items.size() < (1u << 30)) {
             const uint32_t strips = (m_ + 64u * SWMI_RMAX - 1u) / (64u * SWMI_RMAX);
             d.pad = (uint32_t)strip_items.size();
@@ -595,6 +615,12 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
     }
     n_strip_items = strip_items.size();
     n_col_items = col_items.size();
+    if (b->eff_mode == 1) win_off[np] = (uint32_t)std::min<uint64_t>(n_windows, 0xFFFFFFFFu);
+    }
+    if (!prepared && b->eff_mode == 1) {
+        if ((rc = b->d_win_off.reserve((np + 1) * sizeof(uint32_t)))) return rc;
+        HIP_TRY(hipMemcpyAsync(b->d_win_off.p, win_off.data(), (np + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));      // win_off is a local
     }
     if ((rc = b->d_pairs.reserve(np * sizeof(PairDesc)))) return rc;
     if (!prepared && !strip_items.empty()) {
@@ -622,12 +648,13 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
         pr.valid = b->pairs_dev_ptr == b->d_pairs.p;
         pr.lo = lo; pr.hi = hi; pr.work = (const void *)work.data(); pr.params = b->params; pr.mode = b->eff_mode;
         pr.dir_words = dir_words; pr.seam_words = seam_words; pr.max_path = max_path; pr.max_read = max_read;
-        pr.n_strip_items = n_strip_items; pr.n_col_items = n_col_items;
+        pr.n_strip_items = n_strip_items; pr.n_col_items = n_col_items; pr.n_windows = n_windows;
         pr.col_chunks_opt = ctx->col_chunks; pr.reverse_strips = ctx->dbg_reverse_strips != 0;
     }
     if (seam_words) HIP_TRY(hipMemsetAsync(b->d_seam.p, 0, seam_words * 4, ctx->stream));
 
     // cell lists
+    uint32_t cell_cap = ctx->cell_cap;
     std::vector<uint64_t> coff;
     std::vector<uint32_t> ccap;
     uint64_t cells_total = 0;
@@ -643,7 +670,10 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
         HIP_TRY(hipMemcpyAsync(b->d_cells_off.p, coff.data(), np * 8, hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(hipMemcpyAsync(b->d_cells_cap.p, ccap.data(), np * 4, hipMemcpyHostToDevice, ctx->stream));
     } else {
-        cells_total = (uint64_t)np * ctx->cell_cap;
+        // a launch of few pairs can afford long lists: a periodic reference against one read is ONE pair with a tied maximum
+        // per period (EngineerData.java:118), and a list that overflows costs a second run of the pair
+        if (!ctx->cell_cap_set) cell_cap = (uint32_t)std::min<uint64_t>(65536, std::max<uint64_t>(cell_cap, (4ull << 20) / np));
+        cells_total = (uint64_t)np * cell_cap;
     }
     if ((rc = b->d_cells.reserve(std::max<uint64_t>(cells_total, 1) * sizeof(uint2)))) return rc;
 
@@ -692,7 +722,7 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
             fa.dbg_pad = getenv("SWMI_DEBUG_SKIP") ? 1u : 0u;
         }
         fa.n_pairs = (uint32_t)np;
-        fa.cell_cap = ctx->cell_cap;
+        fa.cell_cap = cell_cap;
         fa.match = b->params.match; fa.mismatch = b->params.mismatch; fa.gap = b->params.gap;
         fa.strict = b->params.tie_mode == SWMI_TIE_STRICT;
         fa.mode = b->eff_mode;
@@ -724,6 +754,7 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
         ta.lds_read_words = lds_read_words;
         ta.out_host = nullptr;
         ta.ovf_host = nullptr;
+        ta.win_off = nullptr; ta.q_count = nullptr; ta.q_items = nullptr; ta.q_cap = 0; ta.pad4 = 0;
         const bool zc = ctx->zero_copy != 0;
         if (zc) {
             // results land in pinned host memory while the kernel runs: [overflow word .. | PairOut x np | arena]
@@ -748,7 +779,19 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
             rs.launches++;
         }
         if (ctx->profiling) HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));     // end of the sweep = start of the traceback
-        HIP_TRY(swmi_launch_traceback(&ta, ctx->stream));
+        const bool split = rs.tb_split && b->eff_mode == 1 && n_windows < 0xFFFFFFFFull;
+        if (split) {
+            const uint64_t q_cap = std::min<uint64_t>(std::max<uint64_t>(cells_total, 1), 1ull << 24);
+            if ((rc = b->d_queue.reserve(256 + q_cap * sizeof(uint4)))) return rc;
+            ta.win_off = b->d_win_off.as<uint32_t>();
+            ta.q_count = b->d_queue.as<uint32_t>();
+            ta.q_items = (uint4 *)(b->d_queue.as<uint8_t>() + 256);
+            ta.q_cap = (uint32_t)q_cap;
+            HIP_TRY(hipMemsetAsync(ta.q_count, 0, 4, ctx->stream));
+            HIP_TRY(swmi_launch_traceback_split(&ta, (uint32_t)n_windows, ctx->stream));
+        } else {
+            HIP_TRY(swmi_launch_traceback(&ta, ctx->stream));
+        }
         if (ctx->profiling) HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
 
         // without zero-copy: one D2H of header + pair outputs + as much of the arena as the previous run used
@@ -850,7 +893,12 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
             } else {
                 saved_outs.assign(h + result_out_off(), h + result_out_off() + np * sizeof(PairOut));
             }
-            for (size_t k = 0; k < np; k++) ((PairOut *)saved_outs.data())[k].flags &= ~SWMI_F_ARENA_OVF;
+            for (size_t k = 0; k < np; k++) {
+                PairOut &so = ((PairOut *)saved_outs.data())[k];
+                so.flags &= ~SWMI_F_ARENA_OVF;
+                // the split traceback counts a pair's cells by atomics and flags list overflows itself: start both over
+                if (split && !(so.flags & SWMI_F_DEGENERATE)) { so.n_cells = 0; so.flags &= ~SWMI_F_CELL_OVF; }
+            }
             arena_cap = hdr->used_words + 1024;
             ctx->arena_words_per_pair = std::max<uint64_t>(ctx->arena_words_per_pair, arena_cap / np + 1);
             continue;
@@ -918,24 +966,45 @@ static int ensure_indexed(swmi_batch *b) {
         int rc = parse_records(b->raw.data() + c.at, c.words, c.lo, c.wpos.empty() ? nullptr : &c.wpos, b->ops, recs);
         if (rc) return rc;
     }
-    // group records by pair, ordered by rank (= OptAlignments order for the serial mode)
+    // group records by pair, ordered as OptAlignments lists them: by the rank the traceback kernel computed, or -- records
+    // of the split traceback, which come in any order -- by their cell: row-major (SmithWaterman.java:157-185), or per
+    // anti-diagonal with ascending j for the strict mode (DistributedSW.java:209-239)
     for (auto &w : work) b->pairs[w.pair].count = 0;
     for (auto &r : recs) b->pairs[work[r.wpos].pair].count++;
     uint64_t run = 0;
     for (auto &w : work) { PairRes &pr = b->pairs[w.pair]; pr.first = run; run += pr.count; }
     b->alns.assign(run, HostAln{});
+    std::vector<uint32_t> cursor;
+    const bool strict = b->params.tie_mode == SWMI_TIE_STRICT;
     for (auto &r : recs) {
         PairRes &pr = b->pairs[work[r.wpos].pair];
-        if (r.a.rank >= pr.count) return fail(SWMI_ERR_HIP, "record rank %u out of range", r.a.rank);
-        b->alns[pr.first + r.a.rank] = r.a;
+        if (r.a.rank == SWMI_RANK_BY_CELL) {
+            if (cursor.empty()) cursor.assign(work.size(), 0u);
+            uint32_t &c = cursor[r.wpos];
+            if (c >= pr.count) return fail(SWMI_ERR_HIP, "more records than counted for a pair");
+            b->alns[pr.first + c++] = r.a;
+        } else {
+            if (r.a.rank >= pr.count) return fail(SWMI_ERR_HIP, "record rank %u out of range", r.a.rank);
+            b->alns[pr.first + r.a.rank] = r.a;
+        }
     }
-    for (auto &w : work) {
-        PairRes &pr = b->pairs[w.pair];
+    for (size_t wi = 0; wi < work.size(); wi++) {
+        PairRes &pr = b->pairs[work[wi].pair];
         if (!(pr.flags & SWMI_PAIR_DEGENERATE) && pr.count != pr.n_cells)
-            return fail(SWMI_ERR_HIP, "pair %u: %llu records for %llu max cells", w.pair,
+            return fail(SWMI_ERR_HIP, "pair %u: %llu records for %llu max cells", work[wi].pair,
                         (unsigned long long)pr.count, (unsigned long long)pr.n_cells);
+        if (!cursor.empty() && cursor[wi] > 1) {
+            auto key = [strict](const HostAln &x) {
+                return strict ? (((uint64_t)((uint32_t)x.end_i + (uint32_t)x.end_j)) << 32) | (uint32_t)x.end_j
+                              : ((uint64_t)(uint32_t)x.end_i << 32) | (uint32_t)x.end_j;
+            };
+            std::sort(b->alns.begin() + pr.first, b->alns.begin() + pr.first + pr.count,
+                      [&](const HostAln &x, const HostAln &y) { return key(x) < key(y); });
+        }
+        if (!cursor.empty() && cursor[wi] != 0)
+            for (uint64_t k = 0; k < pr.count; k++) b->alns[pr.first + k].rank = (uint32_t)k;
         // DistributedSW.GetAlignments sorts the collected alignments by beginning (DistributedSW.java:480)
-        if (b->params.tie_mode == SWMI_TIE_STRICT && pr.count > 1)
+        if (strict && pr.count > 1)
             std::stable_sort(b->alns.begin() + pr.first, b->alns.begin() + pr.first + pr.count,
                              [](const HostAln &x, const HostAln &y) { return x.begin < y.begin; });
     }
@@ -979,15 +1048,14 @@ extern "C" int swmi_batch_run(swmi_ctx *ctx, swmi_batch *b, const swmi_params *p
     // pairs with an empty side never enter ScoreMatrix's loops (SmithWaterman.java:157-159): (0, [])
     // The schedule only depends on the sequence lengths and the pipeline mode: built once per batch.
     // mode 1 needs pad rows that cannot outgrow the real cells they derive from: mismatch <= 0 and gap <= 0
-    uint32_t want_mode = ctx->mode;
-    if (ctx->auto_mode && b->auto_choice >= 0 && memcmp(&b->auto_params, p, sizeof(swmi_params)) == 0) want_mode = (uint32_t)b->auto_choice;
-    b->eff_mode = (want_mode == 1 && (p->mismatch > 0 || p->gap > 0)) ? 2u : want_mode;
-    if (ctx->auto_mode && b->eff_mode == 1 && n_pairs >= 64 &&
+    b->eff_mode = (ctx->mode == 1 && (p->mismatch > 0 || p->gap > 0)) ? 2u : ctx->mode;
+    if (ctx->tb_split < 0 && b->eff_mode == 1 && n_pairs >= 64 &&
         (b->auto_choice < 0 || memcmp(&b->auto_params, p, sizeof(swmi_params)) != 0)) {
-        // Automatic pipeline choice, once per batch and parameter set: a sample of the pairs is aligned in mode 1 and
-        // the tied maxima per pair are counted.  Periodic references (the reference's own EngineerData sets: every period
-        // ends in a tied maximum, EngineerData.java:118) make the per-path window re-sweeps of mode 1 cost more than
-        // writing the whole direction field once (mode 0).
+        // Grain of the mode-1 traceback, chosen once per batch and parameter set: a sample of the pairs is aligned and the
+        // tied maxima per pair are counted.  Periodic references (the reference's own EngineerData sets: every period ends
+        // in a tied maximum, EngineerData.java:118) give every pair many alignments; one workgroup per pair then walks them
+        // four at a time while most of the chip idles, so such batches take the split traceback (one wavefront per
+        // window and per alignment, swmi_kernels.hip).
         std::vector<Work> sample;
         const uint64_t want = 48, stride = std::max<uint64_t>(1, n_pairs / want);
         for (uint64_t pi = stride / 2; pi < n_pairs && sample.size() < want; pi += stride) {
@@ -1002,6 +1070,7 @@ extern "C" int swmi_batch_run(swmi_ctx *ctx, swmi_batch *b, const swmi_params *p
         if (!sample.empty()) {
             RunState rs0;
             rs0.ctx = ctx; rs0.b = b;
+            rs0.tb_split = true;                      // (48 pairs: a small launch)
             std::vector<PairOut> o0;
             std::vector<uint32_t> a0;
             uint64_t u0 = 0;
@@ -1009,14 +1078,13 @@ extern "C" int swmi_batch_run(swmi_ctx *ctx, swmi_batch *b, const swmi_params *p
             if (rc) return rc;
             uint64_t cells = 0, live = 0;
             for (auto &o : o0)
-                if (!(o.flags & SWMI_F_DEGENERATE)) { cells += std::min<uint64_t>(o.n_cells, ctx->cell_cap); live++; }
+                if (!(o.flags & SWMI_F_DEGENERATE)) { cells += o.n_cells; live++; }
             if (live && cells * 100 >= (uint64_t)ctx->auto_ties_x100 * live) choice = 0;
             b->prep.valid = false;                    // (the cached preparation was the sample's)
             b->timing = swmi_timing{};
         }
-        b->auto_choice = choice;
+        b->auto_choice = choice;                      // 0: tie-heavy
         b->auto_params = *p;
-        b->eff_mode = (uint32_t)choice;
     }
     if (b->eff_mode == 0) {
         // mode 0's 256-step direction tiles leave the least LDS for the staged alignment: batches with pairs too long for
@@ -1054,6 +1122,9 @@ extern "C" int swmi_batch_run(swmi_ctx *ctx, swmi_batch *b, const swmi_params *p
     const auto h1 = now();
     RunState rs;
     rs.ctx = ctx; rs.b = b;
+    rs.tb_split = b->eff_mode == 1 &&
+                  (ctx->tb_split == 1 || (ctx->tb_split < 0 && (work.size() < 64 || (b->auto_choice == 0 && memcmp(&b->auto_params, p, sizeof(swmi_params)) == 0))));
+    b->tb_split_used = rs.tb_split;
 
     std::vector<PairOut> outs;
     std::vector<uint32_t> arena;

@@ -151,7 +151,17 @@ struct TraceArgs {
     uint32_t       *ovf_host;    // zero-copy results: set to 1 when a record did not fit the (host-mapped) arena
     uint32_t        mode;        // same as FillArgs.mode
     uint32_t        pad2;
+    // split traceback (mode 1, tie-heavy or tiny batches): sw_detect_windows_kernel lists the maximum cells one wavefront
+    // per candidate WINDOW and queues one walk item per cell, sw_walk_items_kernel walks one alignment per wavefront
+    const uint32_t *win_off;     // per pair of the launch: index of its first window among all windows (n_pairs + 1 entries)
+    uint32_t       *q_count;     // walk items queued
+    uint4          *q_items;     // {pair index of the launch, i, j, 0}
+    uint32_t        q_cap;
+    uint32_t        pad4;
 };
+
+#define SWMI_RANK_BY_CELL 0xFFFFFFFFu   // AlnRec.rank of the split traceback: the host orders a pair's records by (end_i, end_j)
+#define SWMI_DETECT_LCAP  64u           // cells one window may hold before the pair is handed to the exact-size re-run
 
 // rows per lane for a read of m bases
 SWMI_HD static inline uint32_t swmi_rows_per_lane(uint32_t m) {

@@ -979,7 +979,8 @@ __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDes
                                                const uint32_t lane, const uint32_t slot, const uint32_t nslots,
                                                uint32_t *__restrict__ lds, uint32_t *__restrict__ lds_tile,
                                                volatile uint32_t *__restrict__ shared, const uint32_t ts,
-                                               uint32_t pre_wlo = 0xFFFFFFFFu, const bool read_staged = false) {
+                                               uint32_t pre_wlo = 0xFFFFFFFFu, const bool read_staged = false,
+                                               const uint4 *__restrict__ one = nullptr) {
     const SeqDesc rd = A.refs[pd.ref_id];
     const SeqDesc qd = A.reads[pd.read_id];
     const uint32_t n = rd.len, m = qd.len;
@@ -1008,7 +1009,7 @@ __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDes
         for (uint32_t w = lane; w < (m + 3u) / 4u; w += WAVE) lds_read[w] = readw[w];
 
     const uint64_t cbase = A.cells_off ? A.cells_off[pd.out_id] : (uint64_t)pd.out_id * A.cell_cap;
-    const uint32_t ncell = (uint32_t)po.n_cells;
+    const uint32_t ncell = one ? 1u : (uint32_t)po.n_cells;          // `one`: walk just this cell (split traceback)
     const uint2 *__restrict__ cells = A.cells + cbase;
 
     // The tied cells are processed in list order; `rank` is the position the reference would list the cell
@@ -1016,10 +1017,11 @@ __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDes
     for (uint32_t base = 0; base < ncell; base += WAVE) {
         const uint32_t idx = base + lane;
         uint2 mine = make_uint2(0, 0);
-        if (idx < ncell) { mine.x = ld_l2(&cells[idx].x); mine.y = ld_l2(&cells[idx].y); }
+        if (one) { mine.x = one->y; mine.y = one->z; }
+        else if (idx < ncell) { mine.x = ld_l2(&cells[idx].x); mine.y = ld_l2(&cells[idx].y); }
         const uint64_t mykey = A.strict ? (((uint64_t)(mine.x + mine.y) << 32) | mine.y)
                                         : (((uint64_t)mine.x << 32) | mine.y);
-        uint32_t rank = 0;
+        uint32_t rank = one ? SWMI_RANK_BY_CELL : 0u;
         if (ncell > 1) {
             for (uint32_t o = 0; o < ncell; ++o) {
                 uint2 c; c.x = ld_l2(&cells[o].x); c.y = ld_l2(&cells[o].y);
@@ -1549,6 +1551,118 @@ sw_traceback_replay_kernel(const TraceArgs A) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// split traceback (mode 1): for batches whose pairs carry many tied maxima (periodic references: the reference's own
+// EngineerData sets, one tied maximum per period) or that have few pairs, one workgroup per pair is the wrong grain --
+// a 128 kbp periodic reference against one read is ONE pair with 1600 alignments.  Here the grain is the window and
+// the alignment:
+//   sw_detect_windows_kernel  one wavefront per checkpoint window of every pair: a window whose maximum equals the
+//                             pair's is re-swept with the cell test on; its cells go to the pair's list (slots reserved
+//                             by one atomicAdd, any order: the host orders a pair's records by cell) and one walk item
+//                             per cell to a global queue;
+//   sw_walk_items_kernel      a fixed grid of wavefronts shares the queue (item w, w + W, ...): one alignment per
+//                             wavefront, windows re-swept one at a time.
+// ------------------------------------------------------------------------------------------------
+#define SWMI_SPLIT_WAVES 4u
+
+extern "C" __global__ void __launch_bounds__(WAVE * SWMI_SPLIT_WAVES)
+sw_detect_windows_kernel(const TraceArgs A) {
+    extern __shared__ uint32_t dw_lds[];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t item = blockIdx.x * SWMI_SPLIT_WAVES + wave;
+    const uint32_t n_items = A.win_off[A.n_pairs];
+    if (item >= n_items) return;
+    // the pair this window belongs to: last p with win_off[p] <= item
+    uint32_t lo = 0, hi = A.n_pairs;
+    while (hi - lo > 1u) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (A.win_off[mid] <= item) lo = mid; else hi = mid;
+    }
+    const uint32_t pair = lo, wloc = item - A.win_off[pair];
+    const PairDesc pd = A.pairs[pair];
+    const PairOut po = A.out[pd.out_id];
+    if (po.flags & SWMI_F_DEGENERATE) return;
+    const SeqDesc rd = A.refs[pd.ref_id];
+    const SeqDesc qd = A.reads[pd.read_id];
+    const uint32_t n = rd.len, m = qd.len;
+    const uint32_t R = swmi_rows_per_lane(m);
+    const uint64_t wblocks = ((uint64_t)n + 63u + 15u) / 16u;
+    const uint32_t n_ck = (uint32_t)((wblocks + SWMI_CK_BLOCKS - 1u) / SWMI_CK_BLOCKS);
+    const uint32_t strip = wloc / n_ck, g = wloc - strip * n_ck;
+    const uint64_t wmax_off = (uint64_t)n_ck * (R + 2) * WAVE;
+    const uint64_t strip_words = wmax_off + (uint64_t)((n_ck + 63u) & ~63u);
+    if ((int)A.dir[pd.dir_off + strip * strip_words + wmax_off + g] != po.score) return;
+
+    // this wave's scratch: the re-swept window (direction bits nobody reads here) and the cells it finds
+    constexpr uint32_t WIN_WORDS = SWMI_CK_BLOCKS * SWMI_RMAX * WAVE;
+    uint32_t *tile = dw_lds + wave * (WIN_WORDS + 2u * SWMI_DETECT_LCAP);
+    uint2 *found = reinterpret_cast<uint2 *>(tile + WIN_WORDS);
+    const uint32_t *__restrict__ refw = A.seqw + rd.boff;
+    const uint32_t *__restrict__ readw = A.seqw + qd.boff;
+    const bool acgt = rd.acgt && qd.acgt && SWMI_SCORES_FIT(A);
+    uint32_t cnt;
+    if (R == 1)      { const StripGeom G = strip_geom<1>(m, n, 1u); cnt = replay_any<1, true>(A, pd, n, m, acgt, refw, readw, G, strip, g * SWMI_CK_BLOCKS, lane, tile, po.score, 0u, found, SWMI_DETECT_LCAP); }
+    else if (R == 2) { const StripGeom G = strip_geom<2>(m, n, 1u); cnt = replay_any<2, true>(A, pd, n, m, acgt, refw, readw, G, strip, g * SWMI_CK_BLOCKS, lane, tile, po.score, 0u, found, SWMI_DETECT_LCAP); }
+    else if (R == 3) { const StripGeom G = strip_geom<3>(m, n, 1u); cnt = replay_any<3, true>(A, pd, n, m, acgt, refw, readw, G, strip, g * SWMI_CK_BLOCKS, lane, tile, po.score, 0u, found, SWMI_DETECT_LCAP); }
+    else             { const StripGeom G = strip_geom<4>(m, n, 1u); cnt = replay_any<4, true>(A, pd, n, m, acgt, refw, readw, G, strip, g * SWMI_CK_BLOCKS, lane, tile, po.score, 0u, found, SWMI_DETECT_LCAP); }
+    if (cnt == 0u) return;                                   // (pad rows can make a window's maximum a value no real cell holds)
+    WAVE_SYNC();
+    const uint64_t cbase = A.cells_off ? A.cells_off[pd.out_id] : (uint64_t)pd.out_id * A.cell_cap;
+    const uint32_t ccap = A.cells_cap ? A.cells_cap[pd.out_id] : A.cell_cap;
+    unsigned long long base = 0;
+    uint32_t qbase = 0;
+    const uint32_t have = cnt < SWMI_DETECT_LCAP ? cnt : SWMI_DETECT_LCAP;
+    if (lane == 0) {
+        base = atomicAdd((unsigned long long *)&A.out[pd.out_id].n_cells, (unsigned long long)cnt);
+        const bool fits = cnt <= SWMI_DETECT_LCAP && base + cnt <= (unsigned long long)ccap;
+        if (fits) {
+            qbase = atomicAdd(A.q_count, have);
+            if (qbase + have > A.q_cap) qbase = 0xFFFFFFFFu;
+        } else {
+            qbase = 0xFFFFFFFFu;
+        }
+        if (qbase == 0xFFFFFFFFu) atomicOr(&A.out[pd.out_id].flags, SWMI_F_CELL_OVF);     // the host re-runs the pair with exact sizes
+    }
+    base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) |
+           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
+    qbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)qbase);
+    if (qbase == 0xFFFFFFFFu) return;
+    uint2 *__restrict__ cells = const_cast<uint2 *>(A.cells) + cbase;
+    for (uint32_t c = lane; c < have; c += WAVE) {
+        const uint2 cell = found[c];
+        cells[base + c] = cell;
+        A.q_items[qbase + c] = make_uint4(pair, cell.x, cell.y, 0u);
+    }
+}
+
+extern "C" __global__ void __launch_bounds__(WAVE * SWMI_SPLIT_WAVES)
+sw_walk_items_kernel(const TraceArgs A) {
+    extern __shared__ uint32_t wi_lds[];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t gw = blockIdx.x * SWMI_SPLIT_WAVES + wave, n_waves = gridDim.x * SWMI_SPLIT_WAVES;
+    // zero-copy results: the pair outputs are final (the detect kernel ended one launch ago)
+    if (A.out_host)
+        for (uint32_t p = gw * WAVE + lane; p < A.n_pairs; p += n_waves * WAVE) A.out_host[p] = A.out[p];
+    uint32_t n_items = *A.q_count;
+    if (n_items > A.q_cap) n_items = A.q_cap;
+    constexpr uint32_t WIN_WORDS = SWMI_CK_BLOCKS * SWMI_RMAX * WAVE;
+    const uint32_t per_wave = A.lds_words + A.lds_read_words + SWMI_TB_REFWIN_WORDS + WIN_WORDS;
+    uint32_t *lds = wi_lds + wave * per_wave;
+    uint32_t *tile = lds + A.lds_words + A.lds_read_words + SWMI_TB_REFWIN_WORDS;
+    for (uint32_t it = gw; it < n_items; it += n_waves) {
+        const uint4 item = A.q_items[it];
+        const PairDesc pd = A.pairs[item.x];
+        PairOut po = A.out[pd.out_id];
+        if (po.flags & (SWMI_F_DEGENERATE | SWMI_F_CELL_OVF)) continue;         // (an overflowed pair is re-run as a whole)
+        const uint32_t R = swmi_rows_per_lane(A.reads[pd.read_id].len);
+        if (R == 1)      traceback_pair<1, 1, false>(A, pd, po, lane, 0u, 1u, lds, tile, nullptr, 1u, 0xFFFFFFFFu, false, &item);
+        else if (R == 2) traceback_pair<2, 1, false>(A, pd, po, lane, 0u, 1u, lds, tile, nullptr, 1u, 0xFFFFFFFFu, false, &item);
+        else if (R == 3) traceback_pair<3, 1, false>(A, pd, po, lane, 0u, 1u, lds, tile, nullptr, 1u, 0xFFFFFFFFu, false, &item);
+        else             traceback_pair<4, 1, false>(A, pd, po, lane, 0u, 1u, lds, tile, nullptr, 1u, 0xFFFFFFFFu, false, &item);
+        WAVE_SYNC();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // host-callable launchers (the runtime in swmi_api.cpp is plain C++)
 // ------------------------------------------------------------------------------------------------
 extern "C" hipError_t swmi_launch_fill(const FillArgs *a, hipStream_t st) {
@@ -1563,6 +1677,22 @@ extern "C" hipError_t swmi_launch_fill(const FillArgs *a, hipStream_t st) {
             hipLaunchKernelGGL(sw_sweep_winmax_cols_kernel, dim3((a->n_col_items + FILL_WAVES - 1) / FILL_WAVES), block, 0, st, *a);
     }
     else                   hipLaunchKernelGGL(sw_fill_score_kernel, grid, block, 0, st, *a);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t swmi_launch_traceback_split(const TraceArgs *a, uint32_t n_windows, hipStream_t st) {
+    if (a->n_pairs == 0) return hipSuccess;
+    const size_t win = (size_t)SWMI_CK_BLOCKS * SWMI_RMAX * WAVE;
+    const size_t det_words = SWMI_SPLIT_WAVES * (win + 2u * SWMI_DETECT_LCAP);
+    if (n_windows)
+        hipLaunchKernelGGL(sw_detect_windows_kernel, dim3((n_windows + SWMI_SPLIT_WAVES - 1) / SWMI_SPLIT_WAVES), dim3(WAVE * SWMI_SPLIT_WAVES),
+                           det_words * sizeof(uint32_t), st, *a);
+    const size_t per_wave = (size_t)a->lds_words + a->lds_read_words + SWMI_TB_REFWIN_WORDS + win;
+    // enough wavefronts to fill the chip several times over, but no more workgroups than there can be items
+    uint32_t groups = (a->q_cap + SWMI_SPLIT_WAVES - 1) / SWMI_SPLIT_WAVES;
+    if (groups > 2048u) groups = 2048u;
+    if (groups < 1u) groups = 1u;
+    hipLaunchKernelGGL(sw_walk_items_kernel, dim3(groups), dim3(WAVE * SWMI_SPLIT_WAVES), SWMI_SPLIT_WAVES * per_wave * sizeof(uint32_t), st, *a);
     return hipGetLastError();
 }
 

@@ -21,23 +21,32 @@ READ_20 = "ACTGACTGACTGACTGACTG"                                                
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--mode", type=int, default=-1, help="pipeline: -1 automatic (default), 0, 1, 2")
+    ap.add_argument("--col-chunks", type=int, default=0, help="0 automatic, 1 never, N force")
     args = ap.parse_args()
     import sparksmithwaterman_amd as sw
     from oracle import sw_oracle as orc
 
     ctx = sw.Context(0)
+    ctx.set_option("mode", args.mode)
+    ctx.set_option("col_chunks", args.col_chunks)
+    print("pipeline option: mode %d, col_chunks %d" % (args.mode, args.col_chunks))
+    modes = []
 
     def run(refs, reads, check):
         b = ctx.upload(refs, reads)
-        b.run()                                   # warm-up
-        t0 = time.perf_counter()
-        b.run()
-        dt = time.perf_counter() - t0
+        b.run()                                   # warm-up (and, in automatic mode, the sampled pipeline choice)
+        dt = 1e9
+        for _ in range(3):
+            t0 = time.perf_counter()
+            b.run()
+            dt = min(dt, time.perf_counter() - t0)
+        modes.append((b.pipeline_mode(), b.timing().col_chunks))
         cells = sum(map(len, refs)) * sum(map(len, reads))
         n_aln = sum(b.n_alignments(p)[0] for p in range(len(refs) * len(reads)))
         cpu = None
         if check:
-            r = orc.bench(refs, reads, nthreads=os.cpu_count() or 1)
+            r = orc.bench(refs, reads, nthreads=min(16, os.cpu_count() or 1))
             assert r["sum_score"] == sum(b.score(p) for p in range(len(refs) * len(reads)))
             assert r["sum_aln"] == n_aln
             cpu = r["cells"] / r["seconds"] / 1e9
@@ -46,11 +55,11 @@ def main():
 
     def table(title, rows):
         print("\n### %s\n" % title)
-        print("| point | cells | alignments | GPU ms | GPU GCUPS | CPU oracle GCUPS (all cores) |")
-        print("|---|---|---|---|---|---|")
-        for name, (cells, dt, n_aln, cpu) in rows:
-            print("| %s | %.3g | %d | %.3f | %.1f | %s |" % (name, cells, n_aln, dt * 1e3, cells / dt / 1e9,
-                                                          "%.2f" % cpu if cpu else "-"))
+        print("| point | cells | alignments | GPU ms | GPU GCUPS | pipeline (mode, column chunks) | CPU oracle GCUPS (all cores) |")
+        print("|---|---|---|---|---|---|---|")
+        for (name, (cells, dt, n_aln, cpu)), md in zip(rows, modes[-len(rows):]):
+            print("| %s | %.3g | %d | %.3f | %.1f | %d, %d | %s |" % (name, cells, n_aln, dt * 1e3, cells / dt / 1e9, md[0], md[1],
+                                                                  "%.2f" % cpu if cpu else "-"))
 
     q = args.quick
     # test 1: number of reads (80 bp) against one 400 bp reference      EngineerData.java:51-79

@@ -19,14 +19,17 @@ READ_80 = "AATTTTAGTCTCTCCCTACCCTTTTGGACAGAGCTTCCTGTCCTCTCATTTCACAGGTTATGCAACAGA
 READ_20 = "ACTGACTGACTGACTGACTG"   # EngineerData.java:29
 
 
-@pytest.fixture(scope="module", params=[(1, 1), (2, 1), (0, 1), (1, 0), (-1, 1)],
-                ids=["mode1-winmax", "mode2-events", "mode0-field", "mode1-d2h-copy", "automatic"])
+@pytest.fixture(scope="module", params=[(1, 1, 0), (2, 1, 0), (0, 1, 0), (1, 0, 0), (-1, 1, -1), (1, 1, 1), (1, 0, 1)],
+                ids=["mode1-winmax", "mode2-events", "mode0-field", "mode1-d2h-copy", "automatic", "mode1-split-traceback",
+                     "mode1-split-d2h-copy"])
 def ctx(request):
     """Every kernel pipeline (include/swmi.h, swmi_set_option "mode"), results written straight to pinned host
-    memory or fetched by a copy."""
+    memory or fetched by a copy, the mode-1 traceback with one workgroup per pair or split per window / alignment
+    (option "tb_split"; -1 lets the library choose)."""
     c = sw.Context(0)
     c.set_option("mode", request.param[0])
     c.set_option("zero_copy", request.param[1])
+    c.set_option("tb_split", request.param[2])
     yield c
     c.close()
 
