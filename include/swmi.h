@@ -93,9 +93,9 @@ void        swmi_default_params(swmi_params *p);
  * tb_split: grain of the mode-1 traceback.  0: one workgroup per pair (lists the maximum cells, then up to four waves walk
  *                the alignments, the others re-sweep windows for them) -- best when pairs have one or a few alignments;
  *                1: split -- one wavefront per checkpoint window lists cells, one wavefront per alignment walks; -1
- *                (default): split for launches of fewer than 64 pairs and for batches in which a sample of the pairs
- *                (aligned once, on the first run of a batch) averages >= auto_ties_x100 / 100 tied maxima per pair --
- *                periodic references, the reference's own EngineerData sets.
+ *                (default): split for launches of fewer than 64 pairs, and for batches of up to 256 pairs in which a sample
+ *                of the pairs (aligned once, on the first run of a batch) averages >= auto_ties_x100 / 100 tied maxima
+ *                per pair -- periodic references, the reference's own EngineerData sets.
  * Further knobs: spin_us (how long a run polls its stream before it blocks, default 2000); col_chunks (0 automatic,
  * 1 never, N > 1 force up to N column chunks per pair: a launch of few pairs with long references is swept by several
  * wavefronts per pair); debug_strip_spins / debug_reverse_strips (tests of the strip pipeline's give-up path). */
