@@ -171,6 +171,40 @@ int  swmi_align_batch(swmi_ctx *ctx, const swmi_params *p,
                       const uint8_t *read_bytes, const uint64_t *read_off, uint32_t n_reads,
                       swmi_batch **out);
 
+/* ---- streaming: a reference set larger than one batch ------------------------------ */
+/* The reference reads a whole FASTA file (InOutOps.GetRefSeqs, InOutOps.java:115-168) and then maps it
+ * (Distribution.java:329-338).  A stream aligns the reads given at open against references that arrive in chunks:
+ * host threads parse / copy chunk k+1 into pinned memory while `slots` workers (each its own HIP stream and device
+ * buffers on the context's GPU) upload the raw bytes, canonicalise them on the GPU, run the full path and keep the
+ * results of chunks k, k-1, ...  After swmi_stream_finish every chunk's results are a swmi_batch to which all
+ * swmi_pair_* / swmi_ref_* accessors apply (reference indices local to the chunk; swmi_stream_chunk gives the offset).
+ * slots = 0 and chunk_bytes = 0 pick the defaults (3 slots, 32 MiB of sequence per chunk). */
+typedef struct swmi_stream swmi_stream;
+typedef struct swmi_stream_stats {
+    double   push_ms;            /* wall time inside swmi_stream_push_file                                  */
+    double   parse_ms;           /* summed over the parser threads                                          */
+    double   upload_ms, run_ms;  /* summed over the slot workers: H2D + encode, sweep + traceback + results */
+    double   gpu_sweep_ms, gpu_traceback_ms;   /* HIP-event times, option "profiling" = 1                   */
+    uint64_t bytes, cells;
+    uint32_t chunks, pad;
+} swmi_stream_stats;
+int      swmi_stream_open(swmi_ctx *ctx, const swmi_params *p, const uint8_t *read_bytes, const uint64_t *read_off,
+                          uint32_t n_reads, uint32_t slots, uint64_t chunk_bytes, swmi_stream **out);
+/* references from memory (copied before the call returns; kept for the alignment strings) */
+int      swmi_stream_push(swmi_stream *s, const uint8_t *ref_bytes, const uint64_t *ref_off, uint32_t n_refs);
+/* references from a FASTA file with GetRefSeqs' line rules (swmi_io.h), parsed segment-wise by parse_threads host
+ * threads (0: 6); the file stays mapped until the stream is closed and a reference's bytes are re-read from it when
+ * one of its alignment strings is asked for.  One file per stream. */
+int      swmi_stream_push_file(swmi_stream *s, const char *path, const char *delimiter, uint32_t parse_threads);
+int      swmi_stream_finish(swmi_stream *s);                  /* blocks until every chunk is done */
+uint64_t swmi_stream_n_refs(const swmi_stream *s);
+uint32_t swmi_stream_n_chunks(const swmi_stream *s);
+int      swmi_stream_chunk(swmi_stream *s, uint32_t k, swmi_batch **batch, uint64_t *first_ref);
+int      swmi_stream_totals(const swmi_stream *s, int32_t *totals, uint64_t n);   /* MapRef totals of all references */
+int      swmi_stream_metadata(const swmi_stream *s, uint64_t ref, char *buf, size_t cap);
+int      swmi_stream_get_stats(const swmi_stream *s, swmi_stream_stats *st);
+void     swmi_stream_close(swmi_stream *s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,9 +6,9 @@ Importing this package does not load the library; the first Context does, and fa
 if it has not been built.
 """
 from ._capi import SwmiError, TIE_SERIAL, TIE_STRICT, PAIR_DEGENERATE, LIB_PATH
-from .aligner import Context, Batch, make_params, DEFAULT_SCORES, DEFAULT_TYPES
+from .aligner import Context, Batch, Stream, make_params, DEFAULT_SCORES, DEFAULT_TYPES
 from .sw import SmithWaterman, DistributedSW, Distribution, default_context
 
-__all__ = ["SwmiError", "TIE_SERIAL", "TIE_STRICT", "PAIR_DEGENERATE", "LIB_PATH", "Context", "Batch",
+__all__ = ["SwmiError", "TIE_SERIAL", "TIE_STRICT", "PAIR_DEGENERATE", "LIB_PATH", "Context", "Batch", "Stream",
            "make_params", "DEFAULT_SCORES", "DEFAULT_TYPES", "SmithWaterman", "DistributedSW",
            "Distribution", "default_context"]

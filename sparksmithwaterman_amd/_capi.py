@@ -32,6 +32,12 @@ class Timing(C.Structure):
                 ("strip_fallbacks", C.c_uint32), ("col_chunks", C.c_uint32)]
 
 
+class StreamStats(C.Structure):
+    _fields_ = [("push_ms", C.c_double), ("parse_ms", C.c_double), ("upload_ms", C.c_double), ("run_ms", C.c_double),
+                ("gpu_sweep_ms", C.c_double), ("gpu_traceback_ms", C.c_double), ("bytes", C.c_uint64), ("cells", C.c_uint64),
+                ("chunks", C.c_uint32), ("pad", C.c_uint32)]
+
+
 # every symbol include/swmi.h declares: (name, restype, argtypes)
 _P = C.c_void_p
 _u8p = C.POINTER(C.c_uint8)
@@ -64,6 +70,17 @@ SYMBOLS = [
     ("swmi_ref_n_match_sites", C.c_int, [_P, C.c_uint32, _u64p]),
     ("swmi_ref_match_site", C.c_int, [_P, C.c_uint32, C.c_uint64, C.POINTER(C.c_int32), C.POINTER(C.c_char_p),
                                       C.POINTER(C.c_char_p), C.POINTER(C.c_uint32)]),
+    ("swmi_stream_open", C.c_int, [_P, C.POINTER(Params), C.c_char_p, _u64p, C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(_P)]),
+    ("swmi_stream_push", C.c_int, [_P, C.c_char_p, _u64p, C.c_uint32]),
+    ("swmi_stream_push_file", C.c_int, [_P, C.c_char_p, C.c_char_p, C.c_uint32]),
+    ("swmi_stream_finish", C.c_int, [_P]),
+    ("swmi_stream_n_refs", C.c_uint64, [_P]),
+    ("swmi_stream_n_chunks", C.c_uint32, [_P]),
+    ("swmi_stream_chunk", C.c_int, [_P, C.c_uint32, C.POINTER(_P), _u64p]),
+    ("swmi_stream_totals", C.c_int, [_P, C.POINTER(C.c_int32), C.c_uint64]),
+    ("swmi_stream_metadata", C.c_int, [_P, C.c_uint64, C.c_char_p, C.c_size_t]),
+    ("swmi_stream_get_stats", C.c_int, [_P, C.POINTER(StreamStats)]),
+    ("swmi_stream_close", None, [_P]),
     ("swmi_align_batch", C.c_int, [_P, C.POINTER(Params), C.c_char_p, _u64p, C.c_uint32, C.c_char_p, _u64p,
                                    C.c_uint32, C.POINTER(_P)]),
 ]

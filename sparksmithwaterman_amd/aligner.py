@@ -2,7 +2,7 @@
 import ctypes as C
 
 from . import _capi
-from ._capi import Params, Timing, check
+from ._capi import Params, Timing, StreamStats, check
 
 DEFAULT_SCORES = (5, -3, -4)              # Distribution.java:36  {match, mismatch, gap}
 DEFAULT_TYPES = ("a", "i", "d", "-")      # Distribution.java:37
@@ -37,6 +37,10 @@ class Context:
         """Sequences -> HBM.  refs/reads: lists of str or bytes."""
         return Batch(self, refs, reads)
 
+    def stream(self, reads, params=None, slots=0, chunk_bytes=0):
+        """A Stream aligning `reads` against references that arrive in chunks (swmi_stream_*)."""
+        return Stream(self, reads, params, slots, chunk_bytes)
+
     def close(self):
         if getattr(self, "_h", None):
             self._lib.swmi_destroy(self._h)
@@ -51,6 +55,15 @@ class Context:
 
 class Batch:
     """refs x reads resident on the GPU (swmi_batch); pair index = ref * n_reads + read."""
+
+    _owned = True
+
+    @classmethod
+    def _view(cls, lib, handle, n_refs, n_reads):
+        """results-only batch owned by a Stream"""
+        b = cls.__new__(cls)
+        b._ctx, b._lib, b._h, b.n_refs, b.n_reads, b._owned = None, lib, handle, n_refs, n_reads, False
+        return b
 
     def __init__(self, ctx, refs, reads):
         self._ctx = ctx
@@ -153,12 +166,80 @@ class Batch:
         return out
 
     def free(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and self._owned:
             self._lib.swmi_batch_free(self._ctx._h, self._h)
-            self._h = None
+        self._h = None
 
     def __del__(self):
         try:
             self.free()
+        except Exception:
+            pass
+
+
+class Stream:
+    """Reads resident, references streamed through the GPU in chunks (include/swmi.h: swmi_stream_*)."""
+
+    def __init__(self, ctx, reads, params=None, slots=0, chunk_bytes=0):
+        self._ctx, self._lib = ctx, ctx._lib
+        self.n_reads = len(reads)
+        qb, qo = _capi.pack(reads)
+        p = params if params is not None else make_params()
+        h = C.c_void_p()
+        check(self._lib.swmi_stream_open(ctx._h, C.byref(p), qb, qo, self.n_reads, int(slots), int(chunk_bytes), C.byref(h)))
+        self._h = h
+
+    def push(self, refs):
+        rb, ro = _capi.pack(refs)
+        check(self._lib.swmi_stream_push(self._h, rb, ro, len(refs)))
+        return self
+
+    def push_file(self, path, delimiter=">gi", parse_threads=0):
+        import os
+        check(self._lib.swmi_stream_push_file(self._h, os.fspath(path).encode(), delimiter.encode("latin-1"), int(parse_threads)))
+        return self
+
+    def finish(self):
+        check(self._lib.swmi_stream_finish(self._h))
+        return self
+
+    def n_refs(self):
+        return self._lib.swmi_stream_n_refs(self._h)
+
+    def chunks(self):
+        """[(first_ref, Batch view), ...] in reference order"""
+        out = []
+        for k in range(self._lib.swmi_stream_n_chunks(self._h)):
+            b, first = C.c_void_p(), C.c_uint64()
+            check(self._lib.swmi_stream_chunk(self._h, k, C.byref(b), C.byref(first)))
+            n_pairs = self._lib.swmi_batch_n_pairs(b)
+            out.append((first.value, Batch._view(self._lib, b, n_pairs // max(self.n_reads, 1), self.n_reads)))
+        return out
+
+    def totals(self):
+        import numpy as np
+        n = self.n_refs()
+        out = np.empty(n, dtype=np.int32)
+        check(self._lib.swmi_stream_totals(self._h, out.ctypes.data_as(C.POINTER(C.c_int32)), n))
+        return out
+
+    def metadata(self, ref):
+        buf = C.create_string_buffer(4096)
+        check(self._lib.swmi_stream_metadata(self._h, ref, buf, 4096))
+        return buf.value.decode("latin-1")
+
+    def stats(self):
+        st = StreamStats()
+        check(self._lib.swmi_stream_get_stats(self._h, C.byref(st)))
+        return st
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.swmi_stream_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
         except Exception:
             pass

@@ -21,10 +21,13 @@
 #include <numeric>
 #include <string>
 #include <thread>
+#include <unordered_map>
+#include <deque>
 #include <vector>
 
 #include "../../include/swmi.h"
 #include "swmi_device.h"
+#include "swmi_io_internal.h"
 
 extern "C" hipError_t swmi_launch_fill(const FillArgs *a, hipStream_t st);
 extern "C" hipError_t swmi_launch_traceback(const TraceArgs *a, hipStream_t st);
@@ -159,6 +162,11 @@ struct swmi_batch {
     uint32_t n_refs = 0, n_reads = 0;
     // original bytes (for string building: characters keep their case) and offsets
     std::vector<uint8_t> ref_bytes, read_bytes;
+    // a streamed chunk keeps no copy of its references: their bytes are read again from the mapped file when an
+    // alignment string is asked for (swmi_stream_push_file)
+    const uint8_t *src_map = nullptr;
+    std::vector<swmi_io_recpos> src_recs;
+    std::unordered_map<uint32_t, std::vector<uint8_t>> src_cache;
     std::vector<uint64_t> ref_off, read_off;
     std::vector<SeqDesc> ref_desc, read_desc;
     // device
@@ -1324,7 +1332,17 @@ extern "C" int swmi_batch_pair_results(const swmi_batch *b, int32_t *scores, uin
 // from the max cell backwards, so the strings are built by walking them in reverse.
 static void materialise(swmi_batch *b, uint64_t pair, HostAln &a, uint64_t slot) {
     const uint32_t r = (uint32_t)(pair / b->n_reads), q = (uint32_t)(pair % b->n_reads);
-    const uint8_t *ref = b->ref_bytes.data() + b->ref_off[r];
+    const uint8_t *ref;
+    if (b->src_map) {
+        auto it = b->src_cache.find(r);
+        if (it == b->src_cache.end()) {
+            it = b->src_cache.emplace(r, std::vector<uint8_t>()).first;
+            swmi_io_read_record(b->src_map, b->src_recs[r], it->second);
+        }
+        ref = it->second.data();
+    } else {
+        ref = b->ref_bytes.data() + b->ref_off[r];
+    }
     const uint8_t *read = b->read_bytes.data() + b->read_off[q];
     std::string &sr = b->str_ref[slot], &sq = b->str_read[slot];
     sr.resize(a.n_ops); sq.resize(a.n_ops);
@@ -1469,4 +1487,371 @@ extern "C" int swmi_ref_match_site(swmi_batch *b, uint32_t ref, uint64_t k, int3
     if (k - deg >= b->ref_sites[ref].size()) return fail(SWMI_ERR_RANGE, "match site %llu out of range", (unsigned long long)k);
     const SiteRef &s = b->ref_sites[ref][k - deg];
     return swmi_pair_alignment(b, s.pair, s.k, begin, nullptr, nullptr, ref_aln, read_aln, len);
+}
+
+
+// ------------------------------------------------------------------------------------------
+// streaming: a reference set too large for one batch, cut into chunks that flow through the GPU
+// ------------------------------------------------------------------------------------------
+// The reference loads a whole FASTA file (InOutOps.GetRefSeqs, src/sw/InOutOps.java:115-168), then maps it
+// (src/sw/Distribution.java:329-338).  Here the file is cut into segments of records; host threads parse segments into
+// pinned buffers while `slots` chunk workers -- each with its own context, HIP stream and device buffers -- upload
+// (raw bytes, canonicalised on the GPU), run the full path and keep the results: chunk k+1's parse and H2D overlap chunk
+// k's kernels and chunk k-1's result handling.  A chunk's results stay accessible as a results-only swmi_batch.
+struct StreamChunk {
+    uint32_t id = 0;
+    PinnedBuf *buf = nullptr;                 // raw sequence bytes of the chunk (pinned: H2D at full PCIe rate)
+    std::vector<uint64_t> off;                // n_refs + 1
+    std::vector<swmi_io_recpos> recs;         // file sources only
+    std::vector<uint8_t> keep;                // memory sources: the bytes kept for the alignment strings
+};
+
+struct swmi_stream {
+    swmi_ctx *owner = nullptr;
+    swmi_params params{};
+    std::vector<uint8_t> read_bytes;
+    std::vector<uint64_t> read_off;
+    uint32_t n_reads = 0;
+    uint64_t chunk_bytes = 32ull << 20;
+    // slots
+    struct Slot { swmi_ctx *ctx = nullptr; swmi_batch *shell = nullptr; std::thread th; };
+    std::vector<Slot> slots;
+    // pinned buffer pool and the queue of parsed chunks
+    std::vector<std::unique_ptr<PinnedBuf>> bufs;
+    std::deque<PinnedBuf *> free_bufs;
+    std::deque<StreamChunk *> ready;
+    std::mutex mu;
+    std::condition_variable cv_free, cv_ready;
+    bool closing = false;
+    int err = 0;
+    std::string err_msg;
+    uint32_t next_id = 0;                      // chunk ids in reference order
+    uint32_t in_flight = 0;
+    std::vector<swmi_batch *> results;         // by chunk id
+    std::vector<uint64_t> first_ref;           // after finish: global index of a chunk's first reference
+    bool finished = false;
+    // file source
+    const uint8_t *map_p = nullptr; size_t map_n = 0; int map_fd = -1;
+    swmi_stream_stats stats{};
+};
+
+static void stream_fail(swmi_stream *s, int rc, const std::string &msg) {
+    std::lock_guard<std::mutex> g(s->mu);
+    if (!s->err) { s->err = rc; s->err_msg = msg; }
+    s->cv_free.notify_all(); s->cv_ready.notify_all();
+}
+
+// one chunk through one slot: upload, run, move the results out of the slot's shell
+static int stream_process(swmi_stream *s, swmi_stream::Slot &sl, StreamChunk *c) {
+    swmi_batch *b = sl.shell;
+    const uint32_t n_refs = (uint32_t)(c->off.size() - 1);
+    int rc;
+    {
+        std::lock_guard<std::mutex> g(sl.ctx->mu);
+        HIP_TRY(hipSetDevice(sl.ctx->device));
+        b->n_refs = n_refs; b->n_reads = s->n_reads;
+        b->ref_off = c->off;
+        b->read_off = s->read_off;
+        if ((uint64_t)n_refs * s->n_reads >= (1ull << 32)) return fail(SWMI_ERR_UNSUPPORTED, "more than 2^32-1 pairs in one chunk");
+        const auto t0 = std::chrono::steady_clock::now();
+        if ((rc = upload_device(sl.ctx, b, sl.ctx->stream, (const uint8_t *)c->buf->p, s->read_bytes.data()))) return rc;
+        const double up = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        std::lock_guard<std::mutex> g2(s->mu);
+        s->stats.upload_ms += up;
+    }
+    const auto t1 = std::chrono::steady_clock::now();
+    if ((rc = swmi_batch_run(sl.ctx, b, &s->params))) return rc;
+    const double run = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
+    // results-only batch of this chunk
+    std::unique_ptr<swmi_batch> r(new swmi_batch);
+    r->n_refs = n_refs; r->n_reads = s->n_reads;
+    r->ref_off = std::move(b->ref_off);
+    r->read_off = s->read_off;
+    r->read_bytes = s->read_bytes;
+    r->ref_desc = b->ref_desc; r->read_desc = b->read_desc;
+    r->params = b->params; r->has_run = true; r->eff_mode = b->eff_mode;
+    r->work = std::move(b->work); b->work.clear(); b->work_mode = -1;
+    r->work_mode = (int)r->eff_mode;
+    r->pairs = std::move(b->pairs);
+    r->raw = std::move(b->raw);
+    r->raw_chunks = std::move(b->raw_chunks);
+    r->indexed = false;
+    r->ref_view_ready.assign(n_refs, 0);
+    r->ref_sites.assign(n_refs, {});
+    r->ref_degenerate.assign(n_refs, 0);
+    r->timing = b->timing;
+    if (!c->recs.empty()) { r->src_map = s->map_p; r->src_recs = std::move(c->recs); }
+    else r->ref_bytes = std::move(c->keep);
+    b->pairs.clear(); b->raw.clear(); b->raw_chunks.clear(); b->has_run = false;
+    std::lock_guard<std::mutex> g(s->mu);
+    if (s->results.size() <= c->id) s->results.resize(c->id + 1, nullptr);
+    s->results[c->id] = r.release();
+    s->stats.run_ms += run;
+    s->stats.gpu_sweep_ms += b->timing.fill_ms;
+    s->stats.gpu_traceback_ms += b->timing.traceback_ms;
+    s->stats.cells += b->timing.cells;
+    s->stats.chunks++;
+    return SWMI_OK;
+}
+
+static void stream_worker(swmi_stream *s, size_t slot) {
+    swmi_stream::Slot &sl = s->slots[slot];
+    for (;;) {
+        StreamChunk *c = nullptr;
+        {
+            std::unique_lock<std::mutex> lk(s->mu);
+            s->cv_ready.wait(lk, [&] { return !s->ready.empty() || s->closing; });
+            if (s->ready.empty()) return;
+            c = s->ready.front();
+            s->ready.pop_front();
+        }
+        int rc = s->err ? s->err : stream_process(s, sl, c);
+        if (rc && !s->err) stream_fail(s, rc, swmi_last_error());
+        {
+            std::lock_guard<std::mutex> g(s->mu);
+            s->free_bufs.push_back(c->buf);
+            s->in_flight--;
+        }
+        s->cv_free.notify_all();
+        delete c;
+    }
+}
+
+extern "C" int swmi_stream_open(swmi_ctx *ctx, const swmi_params *p, const uint8_t *read_bytes, const uint64_t *read_off,
+                                uint32_t n_reads, uint32_t slots, uint64_t chunk_bytes, swmi_stream **out) {
+    if (!ctx || !p || !out) return fail(SWMI_ERR_INVALID, "null argument");
+    *out = nullptr;
+    int rc;
+    if ((rc = check_offsets(read_off, n_reads, "read"))) return rc;
+    if (n_reads && read_off[n_reads] && !read_bytes) return fail(SWMI_ERR_INVALID, "sequence bytes are null");
+    if (slots == 0) slots = 3;
+    if (slots > 8) return fail(SWMI_ERR_INVALID, "at most 8 slots");
+    std::unique_ptr<swmi_stream> s(new swmi_stream);
+    s->owner = ctx;
+    s->params = *p;
+    s->n_reads = n_reads;
+    s->read_off.assign(read_off, read_off + n_reads + 1);
+    s->read_bytes.assign(read_bytes, read_bytes + read_off[n_reads]);
+    if (chunk_bytes) s->chunk_bytes = std::max<uint64_t>(chunk_bytes, 1 << 16);
+    s->slots.resize(slots);
+    for (auto &sl : s->slots) {
+        if ((rc = swmi_create(ctx->device, &sl.ctx))) { swmi_stream_close(s.release()); return rc; }
+        // the slot contexts run what the caller's context would run
+        sl.ctx->cell_cap = ctx->cell_cap; sl.ctx->cell_cap_set = ctx->cell_cap_set; sl.ctx->max_workspace_bytes = ctx->max_workspace_bytes;
+        sl.ctx->profiling = ctx->profiling; sl.ctx->mode = ctx->mode; sl.ctx->zero_copy = ctx->zero_copy;
+        sl.ctx->tb_split = ctx->tb_split; sl.ctx->col_chunks = ctx->col_chunks; sl.ctx->spin_us = 50;
+        sl.shell = new swmi_batch;
+    }
+    // pinned buffers: one being parsed into per parser thread (up to 6), one per slot in flight, two queued
+    const size_t n_bufs = slots + 8;
+    for (size_t k = 0; k < n_bufs; k++) {
+        std::unique_ptr<PinnedBuf> pb(new PinnedBuf);
+        if ((rc = pb->reserve(s->chunk_bytes + (1 << 20)))) { swmi_stream_close(s.release()); return rc; }
+        s->free_bufs.push_back(pb.get());
+        s->bufs.push_back(std::move(pb));
+    }
+    for (size_t k = 0; k < s->slots.size(); k++) s->slots[k].th = std::thread(stream_worker, s.get(), k);
+    *out = s.release();
+    return SWMI_OK;
+}
+
+// takes a free pinned buffer of at least `bytes` (blocks while all are in use)
+static PinnedBuf *stream_take_buf(swmi_stream *s, uint64_t bytes) {
+    PinnedBuf *pb = nullptr;
+    {
+        std::unique_lock<std::mutex> lk(s->mu);
+        s->cv_free.wait(lk, [&] { return !s->free_bufs.empty() || s->err; });
+        if (s->err) return nullptr;
+        pb = s->free_bufs.front();
+        s->free_bufs.pop_front();
+    }
+    if (pb->reserve(bytes)) {                  // (a record longer than a chunk: the buffer grows)
+        stream_fail(s, SWMI_ERR_NOMEM, swmi_last_error());
+        std::lock_guard<std::mutex> g(s->mu);
+        s->free_bufs.push_back(pb);
+        return nullptr;
+    }
+    return pb;
+}
+
+static void stream_submit(swmi_stream *s, StreamChunk *c) {
+    {
+        std::lock_guard<std::mutex> g(s->mu);
+        // chunks are handed to the slots in id order: a later chunk parsed first waits in `ready` (sorted insert)
+        auto it = s->ready.begin();
+        while (it != s->ready.end() && (*it)->id < c->id) ++it;
+        s->ready.insert(it, c);
+        s->in_flight++;
+    }
+    s->cv_ready.notify_one();
+}
+
+extern "C" int swmi_stream_push(swmi_stream *s, const uint8_t *ref_bytes, const uint64_t *ref_off, uint32_t n_refs) {
+    if (!s) return fail(SWMI_ERR_INVALID, "stream is null");
+    if (s->finished) return fail(SWMI_ERR_INVALID, "the stream is finished");
+    int rc;
+    if ((rc = check_offsets(ref_off, n_refs, "reference"))) return rc;
+    if (n_refs && ref_off[n_refs] && !ref_bytes) return fail(SWMI_ERR_INVALID, "sequence bytes are null");
+    // cut the caller's references into chunks of about chunk_bytes
+    uint32_t lo = 0;
+    while (lo < n_refs) {
+        uint32_t hi = lo;
+        while (hi < n_refs && (hi == lo || ref_off[hi + 1] - ref_off[lo] <= s->chunk_bytes)) hi++;
+        const uint64_t bytes = ref_off[hi] - ref_off[lo];
+        PinnedBuf *pb = stream_take_buf(s, std::max<uint64_t>(bytes, 16));
+        if (!pb) return fail(s->err ? s->err : SWMI_ERR_NOMEM, "%s", s->err_msg.c_str());
+        StreamChunk *c = new StreamChunk;
+        c->buf = pb;
+        c->off.resize(hi - lo + 1);
+        for (uint32_t k = lo; k <= hi; k++) c->off[k - lo] = ref_off[k] - ref_off[lo];
+        memcpy(pb->p, ref_bytes + ref_off[lo], bytes);
+        c->keep.assign(ref_bytes + ref_off[lo], ref_bytes + ref_off[hi]);        // for the alignment strings
+        { std::lock_guard<std::mutex> g(s->mu); c->id = s->next_id++; }
+        stream_submit(s, c);
+        lo = hi;
+    }
+    return s->err ? fail(s->err, "%s", s->err_msg.c_str()) : SWMI_OK;
+}
+
+extern "C" int swmi_stream_push_file(swmi_stream *s, const char *path, const char *delimiter, uint32_t parse_threads) {
+    if (!s || !path || !delimiter) return fail(SWMI_ERR_INVALID, "null argument");
+    if (s->finished) return fail(SWMI_ERR_INVALID, "the stream is finished");
+    if (s->map_p) return fail(SWMI_ERR_UNSUPPORTED, "one file per stream");
+    const auto t0 = std::chrono::steady_clock::now();
+    int rc = swmi_io_map(path, &s->map_p, &s->map_n, &s->map_fd);
+    if (rc) return rc;
+    const uint8_t *p = s->map_p;
+    const size_t n = s->map_n;
+    if (n == 0) return fail(SWMI_ERR_INVALID, "reference file has no record: %s", path);                // ref is null at InOutOps.java:153
+    if (swmi_io_next_record(p, n, 0, delimiter) != 0)
+        return fail(SWMI_ERR_INVALID, "reference file does not start with a metadata line: %s", path);  // seq is null at :148
+    // segment boundaries: record starts about chunk_bytes apart
+    std::vector<size_t> cut{0};
+    while (cut.back() < n) {
+        const size_t want = cut.back() + s->chunk_bytes;
+        size_t nxt = want >= n ? n : swmi_io_next_record(p, n, want, delimiter);
+        if (nxt <= cut.back()) nxt = n;
+        cut.push_back(nxt);
+    }
+    const uint32_t n_seg = (uint32_t)(cut.size() - 1);
+    uint32_t id0;
+    { std::lock_guard<std::mutex> g(s->mu); id0 = s->next_id; s->next_id += n_seg; }
+    if (parse_threads == 0) parse_threads = 6;
+    parse_threads = std::min<uint32_t>(parse_threads, std::max<uint32_t>(1, n_seg));
+    std::atomic<uint32_t> next{0};
+    std::string delim(delimiter);
+    auto parser = [&]() {
+        for (;;) {
+            const uint32_t k = next.fetch_add(1);
+            if (k >= n_seg || s->err) return;
+            // segments are parsed in order of their id, and a parser only takes a buffer once the segment before its own
+            // has one: with every buffer in use the oldest chunks are the ones being worked on, never starved by later ones
+            const auto p0 = std::chrono::steady_clock::now();
+            PinnedBuf *pb = stream_take_buf(s, std::max<uint64_t>(cut[k + 1] - cut[k], 16));
+            if (!pb) return;
+            StreamChunk *c = new StreamChunk;
+            c->id = id0 + k;
+            c->buf = pb;
+            int prc = swmi_io_parse_segment(p, cut[k], cut[k + 1], delim.c_str(), (uint8_t *)pb->p, c->off, c->recs);
+            if (prc) {
+                stream_fail(s, prc, swmi_last_error());
+                std::lock_guard<std::mutex> g(s->mu);
+                s->free_bufs.push_back(pb);
+                delete c;
+                return;
+            }
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - p0).count();
+            { std::lock_guard<std::mutex> g(s->mu); s->stats.parse_ms += ms; s->stats.bytes += c->off.back(); }
+            stream_submit(s, c);
+        }
+    };
+    std::vector<std::thread> th;
+    for (uint32_t k = 0; k < parse_threads; k++) th.emplace_back(parser);
+    for (auto &t : th) t.join();
+    s->stats.push_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return s->err ? fail(s->err, "%s", s->err_msg.c_str()) : SWMI_OK;
+}
+
+extern "C" int swmi_stream_finish(swmi_stream *s) {
+    if (!s) return fail(SWMI_ERR_INVALID, "stream is null");
+    {
+        std::unique_lock<std::mutex> lk(s->mu);
+        s->cv_free.wait(lk, [&] { return s->in_flight == 0 || s->err; });
+    }
+    if (s->err) return fail(s->err, "%s", s->err_msg.c_str());
+    if (!s->finished) {
+        s->first_ref.assign(s->results.size() + 1, 0);
+        for (size_t k = 0; k < s->results.size(); k++) {
+            if (!s->results[k]) return fail(SWMI_ERR_HIP, "chunk %zu has no results", k);
+            s->first_ref[k + 1] = s->first_ref[k] + s->results[k]->n_refs;
+        }
+        s->finished = true;
+    }
+    return SWMI_OK;
+}
+
+extern "C" uint64_t swmi_stream_n_refs(const swmi_stream *s) { return s && s->finished ? s->first_ref.back() : 0; }
+extern "C" uint32_t swmi_stream_n_chunks(const swmi_stream *s) { return s && s->finished ? (uint32_t)s->results.size() : 0; }
+
+extern "C" int swmi_stream_chunk(swmi_stream *s, uint32_t k, swmi_batch **batch, uint64_t *first_ref) {
+    if (!s) return fail(SWMI_ERR_INVALID, "stream is null");
+    if (!s->finished) return fail(SWMI_ERR_INVALID, "call swmi_stream_finish first");
+    if (k >= s->results.size()) return fail(SWMI_ERR_RANGE, "chunk %u out of range", k);
+    if (batch) *batch = s->results[k];
+    if (first_ref) *first_ref = s->first_ref[k];
+    return SWMI_OK;
+}
+
+extern "C" int swmi_stream_totals(const swmi_stream *s, int32_t *totals, uint64_t n) {
+    if (!s || !totals) return fail(SWMI_ERR_INVALID, "null argument");
+    if (!s->finished) return fail(SWMI_ERR_INVALID, "call swmi_stream_finish first");
+    if (n != s->first_ref.back()) return fail(SWMI_ERR_RANGE, "the stream holds %llu references, not %llu",
+                                               (unsigned long long)s->first_ref.back(), (unsigned long long)n);
+    for (size_t k = 0; k < s->results.size(); k++) {
+        int rc = swmi_ref_totals(s->results[k], totals + s->first_ref[k], s->results[k]->n_refs);
+        if (rc) return rc;
+    }
+    return SWMI_OK;
+}
+
+// metadata line of a streamed reference (file sources), copied into buf (NUL-terminated, truncated to cap)
+extern "C" int swmi_stream_metadata(const swmi_stream *s, uint64_t ref, char *buf, size_t cap) {
+    if (!s || !buf || !cap) return fail(SWMI_ERR_INVALID, "null argument");
+    if (!s->finished) return fail(SWMI_ERR_INVALID, "call swmi_stream_finish first");
+    if (ref >= s->first_ref.back()) return fail(SWMI_ERR_RANGE, "reference %llu out of range", (unsigned long long)ref);
+    const size_t k = (size_t)(std::upper_bound(s->first_ref.begin(), s->first_ref.end(), ref) - s->first_ref.begin()) - 1;
+    const swmi_batch *b = s->results[k];
+    buf[0] = 0;
+    if (b->src_map) {
+        const swmi_io_recpos &r = b->src_recs[ref - s->first_ref[k]];
+        const size_t len = std::min<size_t>(cap - 1, r.meta_len);
+        memcpy(buf, b->src_map + r.meta_pos, len);
+        buf[len] = 0;
+    }
+    return SWMI_OK;
+}
+
+extern "C" int swmi_stream_get_stats(const swmi_stream *s, swmi_stream_stats *st) {
+    if (!s || !st) return fail(SWMI_ERR_INVALID, "null argument");
+    *st = s->stats;
+    return SWMI_OK;
+}
+
+extern "C" void swmi_stream_close(swmi_stream *s) {
+    if (!s) return;
+    {
+        std::lock_guard<std::mutex> g(s->mu);
+        s->closing = true;
+    }
+    s->cv_ready.notify_all();
+    for (auto &sl : s->slots) if (sl.th.joinable()) sl.th.join();
+    for (auto *c : s->ready) { delete c; }
+    for (auto &sl : s->slots) {
+        if (sl.shell) swmi_batch_free(sl.ctx, sl.shell);
+        if (sl.ctx) swmi_destroy(sl.ctx);
+    }
+    for (auto *r : s->results) if (r) swmi_batch_free(nullptr, r);
+    for (auto &pb : s->bufs) pb->release();
+    if (s->map_p) swmi_io_unmap(s->map_p, s->map_n, s->map_fd);
+    delete s;
 }

@@ -134,6 +134,82 @@ extern "C" int swmi_io_read_refs(const char *path, const char *delimiter, swmi_s
     return SWMI_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// segment-wise GetRefSeqs for the streaming path (swmi_stream_push_file, swmi_api.cpp): the same line rules, applied to
+// one slice of the mapped file at a time so that several host threads parse while the GPU aligns earlier slices.
+// ------------------------------------------------------------------------------------------------
+#include "swmi_io_internal.h"
+
+int swmi_io_map(const char *path, const uint8_t **p, size_t *n, int *fd) {
+    Mapped m;
+    int rc = map_file(path, m);
+    if (rc) return rc;
+    *p = m.p; *n = m.n; *fd = m.fd;
+    m.p = nullptr; m.n = 0; m.fd = -1;          // ownership moves to the caller
+    return SWMI_OK;
+}
+
+void swmi_io_unmap(const uint8_t *p, size_t n, int fd) {
+    if (p && n) munmap((void *)p, n);
+    if (fd >= 0) close(fd);
+}
+
+// first position >= from that starts a metadata line (a line beginning with the delimiter), or n
+size_t swmi_io_next_record(const uint8_t *p, size_t n, size_t from, const char *delim) {
+    const size_t dlen = strlen(delim);
+    size_t pos = from;
+    if (pos > 0 && pos < n) {
+        // move to the start of the next line unless `from` already is one
+        const uint8_t prev = p[pos - 1];
+        const bool at_start = prev == '\n' || (prev == '\r' && p[pos] != '\n');
+        if (!at_start) {
+            size_t b, e;
+            next_line(p, n, pos, b, e);
+        }
+    }
+    while (pos < n) {
+        size_t b, e, q = pos;
+        if (!next_line(p, n, q, b, e)) break;
+        if (is_metadata(p + b, e - b, delim, dlen)) return b;
+        pos = q;
+    }
+    return n;
+}
+
+// parses the records of [from, to) -- `from` must be a metadata line, `to` a record start or n -- appending the sequence
+// bytes to dst (capacity >= to - from) exactly as GetRefSeqs does (every non-metadata line untrimmed, InOutOps.java:127-150)
+int swmi_io_parse_segment(const uint8_t *p, size_t from, size_t to, const char *delim, uint8_t *dst,
+                          std::vector<uint64_t> &off, std::vector<swmi_io_recpos> &recs) {
+    const size_t dlen = strlen(delim);
+    size_t pos = from, b, e;
+    uint64_t at = 0;
+    off.clear(); recs.clear();
+    off.push_back(0);
+    bool open_rec = false;
+    while (pos < to && next_line(p, to, pos, b, e)) {
+        if (is_metadata(p + b, e - b, delim, dlen)) {
+            if (open_rec) { off.push_back(at); recs.back().seq_end = b; }
+            swmi_io_recpos r;
+            r.meta_pos = b; r.meta_len = e - b; r.seq_pos = pos; r.seq_end = to;
+            recs.push_back(r);
+            open_rec = true;
+        } else {
+            if (!open_rec) return swmi_io_fail(SWMI_ERR_INVALID, "reference file does not start with a metadata line");
+            memcpy(dst + at, p + b, e - b);
+            at += e - b;
+        }
+    }
+    if (open_rec) off.push_back(at);
+    return SWMI_OK;
+}
+
+// the sequence of one record again (for the alignment strings of a streamed reference: the stream keeps no copy of the bytes)
+void swmi_io_read_record(const uint8_t *p, const swmi_io_recpos &r, std::vector<uint8_t> &out) {
+    out.clear();
+    size_t pos = r.seq_pos, b, e;
+    while (pos < r.seq_end && next_line(p, r.seq_end, pos, b, e)) out.insert(out.end(), p + b, p + e);
+}
+
 extern "C" uint32_t swmi_seqset_count(const swmi_seqset *s) { return s ? (uint32_t)(s->off.size() - 1) : 0; }
 extern "C" const uint8_t *swmi_seqset_bytes(const swmi_seqset *s) { return s ? s->bytes.data() : nullptr; }
 extern "C" const uint64_t *swmi_seqset_offsets(const swmi_seqset *s) { return s ? s->off.data() : nullptr; }

@@ -133,3 +133,72 @@ def test_drivers_write_the_control_drivers_result_files(tmp_path):
     sw.Distribution.NoDistribution(ctx).call([str(ref_dir), str(in_dir), ">gi", str(out2), "res", ".out"], ([5, -3, -4], ["a", "i", "d", "-"]))
     assert open(out2 / "res1.out", newline="").read().split(os.linesep, 1)[1] == expect[0].split(os.linesep, 1)[1]
     ctx.close()
+
+
+def _write_fasta(path, refs, width=80):
+    with open(path, "w") as f:
+        for k, r in enumerate(refs):
+            f.write(">gi|ref%d\n" % k)
+            for x in range(0, len(r), width):
+                f.write(r[x:x + width] + "\n")
+
+
+@pytest.mark.gpu
+def test_stream_from_memory_matches_one_batch(tmp_path):
+    """swmi_stream_push: the references cut into many small chunks over two slots give, chunk by chunk, what one batch
+    gives -- totals, every pair's score and alignment count, and the alignment strings (from the bytes the stream kept)."""
+    import numpy as np
+    from sparksmithwaterman_amd import synth
+    from oracle import sw_oracle as orc
+    refs, reads = synth.config_ncbi(1500, read_len=150, seed=21)
+    reads = reads + [refs[7][30:130].decode()]
+    ctx = sw.Context(0)
+    b = ctx.upload(refs, reads).run()
+    want_sc, want_na = b.pair_results()
+    st = ctx.stream(reads, slots=2, chunk_bytes=200 << 10)
+    st.push(refs[:900]).push(refs[900:]).finish()
+    assert st.n_refs() == len(refs)
+    chunks = st.chunks()
+    assert len(chunks) > 8 and chunks[0][0] == 0
+    assert list(st.totals()) == list(b.ref_totals())
+    got_sc = np.concatenate([c.pair_results()[0] for _, c in chunks])
+    got_na = np.concatenate([c.pair_results()[1] for _, c in chunks])
+    assert list(got_sc) == list(want_sc) and list(got_na) == list(want_na)
+    for first, c in chunks[::3]:
+        r = first + c.n_refs - 1
+        assert c.ref_match_sites(c.n_refs - 1) == orc.map_ref((">gi|x", refs[r]), reads)[1][1]
+    st.close()
+    b.free()
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_stream_from_fasta_file_100k_references(tmp_path):
+    """configs[2] shape through the streamed path: a FASTA file of 100,000 NCBI-shaped references (log-normal
+    lengths, median 1,609 bp), parsed segment-wise into pinned memory, canonicalised on the GPU, aligned chunk by chunk on
+    three overlapping slots.  Checked against the oracle's multi-threaded pass over the same 100,000 pairs: sum of scores, sum of
+    alignment counts, the winner and its alignments (whose bytes are re-read from the mapped file)."""
+    import numpy as np
+    from sparksmithwaterman_amd import synth
+    from oracle import sw_oracle as orc
+    refs, reads = synth.config_ncbi(100000, read_len=150, seed=2)
+    path = tmp_path / "refs.fa"
+    _write_fasta(path, [r.decode() for r in refs])
+    ctx = sw.Context(0)
+    st = ctx.stream(reads, slots=3, chunk_bytes=16 << 20)
+    st.push_file(path, ">gi", 6).finish()
+    assert st.n_refs() == len(refs)
+    totals = st.totals()
+    n_aln = sum(int(c.pair_results()[1].sum()) for _, c in st.chunks())
+    ob = orc.bench(refs, reads, nthreads=16)
+    assert int(totals.astype(np.int64).sum()) == ob["sum_score"]
+    assert n_aln == ob["sum_aln"]
+    w = int(totals.argmax())
+    assert st.metadata(w) == ">gi|ref%d" % w
+    es, ea = orc.opt_alignments((refs[w], reads[0]))
+    for first, c in st.chunks():
+        if first <= w < first + c.n_refs:
+            assert c.score(w - first) == es and c.alignments(w - first) == ea
+    assert st.stats().chunks == len(st.chunks()) >= 10
+    st.close()
+    ctx.close()
