@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libswmi.so")
+# (SWMI_LIB: another build of the same sources, e.g. the -DSWMI_CK_BLOCKS=4u variant of tools/build_variants.sh)
+LIB_PATH = os.environ.get("SWMI_LIB") or os.path.join(_HERE, "lib", "libswmi.so")
 
 TIE_SERIAL = 0
 TIE_STRICT = 1

@@ -175,6 +175,7 @@ struct swmi_batch {
     DevBuf d_strip_items, d_progress;       // mode 1: strip-per-wavefront sweep of long reads
     DevBuf d_col_items;                     // mode 1: column chunks of single-strip pairs
     DevBuf d_win_off, d_queue;              // split traceback: per-pair window offsets, walk-item queue
+    bool views_built = false;               // some MapRef view of the last run was built (they are reset by the next run)
     bool tb_split_used = false;             // the last run used the split traceback
     bool acgt_known = false;                // ref_desc/read_desc[].acgt fetched back from the device (set there by the encode kernel)
     PinnedBuf h_result;
@@ -599,7 +600,9 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
             const uint32_t step_w = 16u * SWMI_CK_BLOCKS;                       // anti-diagonal steps (= columns of lane 0) per window
             uint64_t chunks = std::min<uint64_t>(chunk_budget, n_ / std::max<uint64_t>(span + 64, 256));
             chunks = std::min<uint64_t>(chunks, n_ck);
-            if (chunks >= 2) {
+            static const bool dbg_one = getenv("SWMI_DEBUG_ONE_CHUNK") != nullptr;      // diagnostics: every pair through the chunk kernel, one chunk
+            if (dbg_one) chunks = 1;
+            if (chunks >= 2 || dbg_one) {
                 const uint32_t wpc = (uint32_t)((n_ck + chunks - 1) / chunks);   // windows per chunk
                 const size_t first = col_items.size();
                 for (uint32_t g_lo = 0; g_lo < n_ck; g_lo += wpc) {
@@ -610,7 +613,7 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
                     // a chunk that is not the last must end where lane 0 is still inside the reference
                     if (ci.g_hi < n_ck && (uint64_t)ci.g_hi * step_w > n_) ci.g_hi = n_ck;
                     const int64_t c0 = (int64_t)g_lo * step_w - 64 - (int64_t)span - 1;
-                    ci.col0 = g_lo == 0 || c0 <= 0 ? 0u : (uint32_t)(c0 & ~(int64_t)31);
+                    ci.col0 = g_lo == 0 || c0 <= 0 ? 0u : (uint32_t)(c0 / step_w * step_w);   // (on a window boundary: checkpoints stay aligned)
                     col_items.push_back(ci);
                     if (ci.g_hi == n_ck) break;
                 }
@@ -880,6 +883,22 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
             }
             fprintf(stderr, "[swmi fill dbg] pairs=%zu slow-path entries mean=%.1f max=%llu; wave ticks mean=%.0f min=%llu max=%llu\n",
                     np, (double)ev / np, evmax, (double)cyc / np, cmin, cmax);
+            if (b->eff_mode == 1) {
+                // the fast sweep stores HW_ID | XCC_ID << 32 instead of an event count: placement of the waves
+                std::unordered_map<unsigned long long, int> per_simd, per_cu;
+                for (size_t k = 0; k < np; k++) {
+                    const unsigned long long hw = d[2 * k] & 0xFFFFFFFFull, xcc = (d[2 * k] >> 32) & 0xF;
+                    const unsigned long long simd = (hw >> 4) & 3, cu = (hw >> 8) & 15, sh = (hw >> 12) & 1, se = (hw >> 13) & 7;
+                    const unsigned long long cukey = (xcc << 16) | (se << 8) | (sh << 4) | cu;
+                    per_cu[cukey]++; per_simd[(cukey << 4) | simd]++;
+                }
+                int h_simd[9] = {0}, h_cu[17] = {0};
+                for (auto &kv : per_simd) h_simd[std::min(kv.second, 8)]++;
+                for (auto &kv : per_cu) h_cu[std::min(kv.second, 16)]++;
+                fprintf(stderr, "[swmi fill dbg] placement: %zu CUs, %zu SIMDs used; SIMDs by waves held: 1:%d 2:%d 3:%d 4+:%d; CUs by waves held: 1-4:%d 5-8:%d 9+:%d\n",
+                        per_cu.size(), per_simd.size(), h_simd[1], h_simd[2], h_simd[3], h_simd[4] + h_simd[5] + h_simd[6] + h_simd[7] + h_simd[8],
+                        h_cu[1] + h_cu[2] + h_cu[3] + h_cu[4], h_cu[5] + h_cu[6] + h_cu[7] + h_cu[8], h_cu[9] + h_cu[10] + h_cu[11] + h_cu[12] + h_cu[13] + h_cu[14] + h_cu[15] + h_cu[16]);
+            }
         }
         const uint8_t *h = (const uint8_t *)b->h_result.p;
         ArenaHdr hdr_copy{};
@@ -931,7 +950,8 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
                                   hipMemcpyDeviceToHost));
             ctx->arena_copy_wpp = arena_used * 5 / (4 * np) + 2;
         }
-        arena_copy.assign((const uint32_t *)(h + a_off), (const uint32_t *)(h + a_off) + arena_used);
+        // the record stream is appended to the caller's vector (the batch's raw stream): one copy out of the pinned block
+        arena_copy.insert(arena_copy.end(), (const uint32_t *)(h + a_off), (const uint32_t *)(h + a_off) + arena_used);
         for (auto &o : outs) o.flags &= ~SWMI_F_ARENA_OVF;
         rs.copyout_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - c2).count();
         return SWMI_OK;
@@ -1048,9 +1068,12 @@ extern "C" int swmi_batch_run(swmi_ctx *ctx, swmi_batch *b, const swmi_params *p
     b->pairs.assign(n_pairs, PairRes{});
     b->alns.clear(); b->ops.clear(); b->str_ref.clear(); b->str_read.clear();
     b->raw.clear(); b->raw_chunks.clear(); b->indexed = false;
-    b->ref_view_ready.assign(n_refs, 0);
-    b->ref_sites.assign(n_refs, {});
-    b->ref_degenerate.assign(n_refs, 0);
+    if (b->views_built || b->ref_view_ready.size() != n_refs) {     // (a run nobody read MapRef views of leaves them as they are)
+        b->ref_view_ready.assign(n_refs, 0);
+        b->ref_sites.assign(n_refs, {});
+        b->ref_degenerate.assign(n_refs, 0);
+        b->views_built = false;
+    }
     b->timing = swmi_timing{};
 
     // pairs with an empty side never enter ScoreMatrix's loops (SmithWaterman.java:157-159): (0, [])
@@ -1153,7 +1176,8 @@ extern "C" int swmi_batch_run(swmi_ctx *ctx, swmi_batch *b, const swmi_params *p
         }
         dir_bytes += words * 4;
         uint64_t used = 0;
-        int rc = run_chunk(rs, work, lo, hi, nullptr, outs, arena, used);
+        const size_t raw_at = b->raw.size();
+        int rc = run_chunk(rs, work, lo, hi, nullptr, outs, b->raw, used);
         if (rc) return rc;
         for (size_t k = 0; k < hi - lo; k++) {
             PairRes &pr = b->pairs[work[lo + k].pair];
@@ -1162,8 +1186,7 @@ extern "C" int swmi_batch_run(swmi_ctx *ctx, swmi_batch *b, const swmi_params *p
             pr.n_cells = outs[k].n_cells;
             if (outs[k].flags & SWMI_F_CELL_OVF) ovf.push_back(lo + k);
         }
-        b->raw_chunks.push_back(swmi_batch::RawChunk{b->raw.size(), (size_t)used, lo, {}});
-        b->raw.insert(b->raw.end(), arena.begin(), arena.begin() + used);
+        b->raw_chunks.push_back(swmi_batch::RawChunk{raw_at, (size_t)used, lo, {}});
         lo = hi;
     }
 
@@ -1182,13 +1205,13 @@ extern "C" int swmi_batch_run(swmi_ctx *ctx, swmi_batch *b, const swmi_params *p
                 hi2++;
             }
             uint64_t used = 0;
-            int rc = run_chunk(rs, w2, lo2, hi2, &exact, outs, arena, used);
+            const size_t raw_at2 = b->raw.size();
+            int rc = run_chunk(rs, w2, lo2, hi2, &exact, outs, b->raw, used);
             if (rc) return rc;
-            swmi_batch::RawChunk rc2{b->raw.size(), (size_t)used, lo2, {}};
+            swmi_batch::RawChunk rc2{raw_at2, (size_t)used, lo2, {}};
             rc2.wpos.resize(hi2 - lo2);
             for (size_t k = 0; k < hi2 - lo2; k++) rc2.wpos[k] = (uint32_t)ovf[lo2 + k];   // chunk-local id -> position in `work`
             b->raw_chunks.push_back(std::move(rc2));
-            b->raw.insert(b->raw.end(), arena.begin(), arena.begin() + used);
             for (size_t k = 0; k < hi2 - lo2; k++) b->pairs[w2[lo2 + k].pair].n_cells = outs[k].n_cells;
             for (size_t k = 0; k < hi2 - lo2; k++)
                 if (outs[k].flags & SWMI_F_CELL_OVF)
@@ -1448,6 +1471,7 @@ extern "C" int swmi_ref_totals(const swmi_batch *b, int32_t *totals, uint32_t n)
 
 static void build_ref_view(swmi_batch *b, uint32_t ref) {
     if (b->ref_view_ready[ref]) return;
+    b->views_built = true;
     std::vector<SiteRef> &v = b->ref_sites[ref];
     uint64_t deg = 0;
     for (uint32_t q = 0; q < b->n_reads; q++) {

@@ -30,7 +30,9 @@
 
 #define SWMI_SEQ_PAD_WORDS 24u
 #define SWMI_RMAX          4          // rows per lane in the widest kernel variant
+#ifndef SWMI_CK_BLOCKS
 #define SWMI_CK_BLOCKS     2u         // mode 1: a lane-state checkpoint every 2 blocks = 32 anti-diagonal steps
+#endif                                 // (-DSWMI_CK_BLOCKS=4u builds the 64-step variant measured in profiles/r02/ck_blocks.md)
 #define SWMI_CODE_PAD      0x1FFu     // never equals a base code (codes are 0..255)
 
 // op codes of an alignment record (2 bits per traceback step)

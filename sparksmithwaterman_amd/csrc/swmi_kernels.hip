@@ -410,12 +410,6 @@ __device__ __forceinline__ void fill_pair(const FillArgs &A, const PairDesc pd, 
 
     const uint32_t s_begin = PIPE ? my_strip : 0u, s_end = PIPE ? my_strip + 1u : G.n_strips;
     uint32_t *__restrict__ progress = PIPE ? A.progress + pd.pad : nullptr;
-    if (PIPE && my_strip == 0u && lane == 0) {
-        // the pair's result is assembled by atomics from all its strips: start from zero (every other strip touches it
-        // only after it has seen progress of this one)
-        __hip_atomic_store(&A.out[pd.out_id].score, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store((unsigned long long *)&A.out[pd.out_id].n_cells, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
     for (uint32_t s = s_begin; s < s_end; ++s) {
         const uint32_t row0 = s * G.rps + lane * R;        // 0-based first row of this lane
         const uint32_t rows_left = m - s * G.rps;
@@ -527,19 +521,9 @@ __device__ __forceinline__ void fill_pair(const FillArgs &A, const PairDesc pd, 
     }
 
     if (PIPE) {
-        // combine the strips: maximum by atomicMax, the last strip to finish completes the record
-        if (lane == 0) {
-            PairOut *o = &A.out[pd.out_id];
-            if (pair_max > 0) atomicMax(&o->score, pair_max);
-            __threadfence();
-            const unsigned long long done = atomicAdd((unsigned long long *)&o->n_cells, 1ull);
-            if (done + 1ull == (unsigned long long)G.n_strips) {
-                __threadfence();
-                const int best = __hip_atomic_load(&o->score, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (best <= 0) { o->flags = SWMI_F_DEGENERATE; o->n_cells = (uint64_t)m * n; }
-                else           { o->flags = 0u; o->n_cells = 0; }
-            }
-        }
+        // combine the strips: one atomicMax each into the record sw_sweep_winmax_kernel zeroed one launch earlier; the
+        // traceback kernels complete it (finish_pair).  No fence: see sweep_fast.
+        if (lane == 0 && pair_max > 0) atomicMax(&A.out[pd.out_id].score, pair_max);
         return;
     }
     if (lane == 0) {
@@ -612,7 +596,7 @@ __device__ __forceinline__ void sweep_fast(const FillArgs &A, const PairDesc pd,
     const uint32_t col0 = COLS ? ci.col0 : 0u;
     const uint32_t g_lo = COLS ? ci.g_lo : 0u, g_hi = COLS ? ci.g_hi : G.n_ck;
     const bool last = g_hi >= G.n_ck;
-    const uint32_t n = (last ? n_full : 32u * g_hi) - col0;               // columns of this wavefront's (virtual) reference
+    const uint32_t n = (last ? n_full : 16u * SWMI_CK_BLOCKS * g_hi) - col0;   // columns of this wavefront's (virtual) reference
     const uint32_t *__restrict__ refw = A.seqw + rd.boff + (col0 >> 2);
     const uint32_t *__restrict__ readw = A.seqw + qd.boff;
     const uint32_t lact = m >= G.rps ? WAVE : (m + R - 1) / R;           // lanes holding rows
@@ -623,6 +607,7 @@ __device__ __forceinline__ void sweep_fast(const FillArgs &A, const PairDesc pd,
     const int one = 1;
     int pair_max = 0;
 
+    const unsigned long long dbg_t0 = A.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
     SweepState<R> S;
 #pragma unroll
     for (int k = 0; k < R; ++k) {
@@ -695,19 +680,18 @@ __device__ __forceinline__ void sweep_fast(const FillArgs &A, const PairDesc pd,
         if (gl >= g_lo) close_window(gl);
     }
     if (lane != 0) return;
+    if (A.dbg) {      // diagnostics: where the wave ran (HW_ID: wave, SIMD, CU, SE ...) and how long
+        A.dbg[2 * pd.out_id] = (unsigned long long)__builtin_amdgcn_s_getreg((4 /*HW_REG_HW_ID*/) | (0 << 6) | (31 << 11)) |
+                               ((unsigned long long)__builtin_amdgcn_s_getreg((20 /*HW_REG_XCC_ID*/) | (0 << 6) | (31 << 11)) << 32);
+        A.dbg[2 * pd.out_id + 1] = __builtin_amdgcn_s_memtime() - dbg_t0;
+    }
     PairOut *o = &A.out[pd.out_id];
     if (COLS) {
-        // combine the chunks: maximum by atomicMax (the record was zeroed by sw_sweep_winmax_kernel, one launch earlier),
-        // the last chunk to finish completes the record
+        // combine the chunks: ONE atomicMax each (the record was zeroed by sw_sweep_winmax_kernel, one launch earlier) and
+        // nothing else -- no completion count, no fence: a fence here writes back the XCD's L2, full of the checkpoints just
+        // stored, and cost every chunk's launch ~30 us (profiles/r02/col_chunks.md).  The traceback kernels, one launch
+        // later, read the final maximum and mark the pair degenerate when it is 0 (finish_pair).
         if (pair_max > 0) atomicMax(&o->score, pair_max);
-        __threadfence();
-        const unsigned long long done = atomicAdd((unsigned long long *)&o->n_cells, 1ull);
-        if (done + 1ull == (unsigned long long)(pd.pad & ~SWMI_PAD_COLS)) {
-            __threadfence();
-            const int best = __hip_atomic_load(&o->score, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (best <= 0) { o->flags = SWMI_F_DEGENERATE; o->n_cells = (uint64_t)m * n_full; }
-            else           { o->flags = 0u; o->n_cells = 0; }
-        }
         return;
     }
     PairOut v;                 // the cells holding the maximum are listed by the traceback kernel (n_cells follows there)
@@ -747,7 +731,11 @@ __device__ __forceinline__ void fill_entry(const FillArgs &A) {
     const PairDesc pd = A.pairs[pair];
     const SeqDesc rd = A.refs[pd.ref_id];
     const SeqDesc qd = A.reads[pd.read_id];
-    if (MODE == SWMI_MODE_WINMAX && A.skip_multi && qd.len > WAVE * SWMI_RMAX) return;   // swept strip by strip, see below
+    if (MODE == SWMI_MODE_WINMAX && A.skip_multi && qd.len > WAVE * SWMI_RMAX) {
+        // swept strip by strip (sw_sweep_winmax_strips_kernel, next launch): start the record its strips complete by atomics
+        if (lane == 0) { PairOut z; z.score = 0; z.flags = 0u; z.n_cells = 0; A.out[pd.out_id] = z; }
+        return;
+    }
     // profile lookup needs both sequences pure ACGT and scores that fit a signed byte
     const bool acgt = rd.acgt && qd.acgt &&
                       SWMI_SCORES_FIT(A);
@@ -830,7 +818,11 @@ sw_sweep_winmax_cols_kernel(const FillArgs A) {
 #define SWMI_TB_BLOCKS 16u
 #define SWMI_TB_REFWIN_WORDS 96u      // (16*16 + 63) / 4 + slack
 #define SWMI_TB_SLOTS 4u
+#if SWMI_CK_BLOCKS > 2
+#define SWMI_TB_WAVES 4u            // (64-step windows: a team's span of 4 windows is what the reference-window staging holds)
+#else
 #define SWMI_TB_WAVES 8u            // mode 1: most waves per workgroup (= per pair) of the traceback kernel; the launcher picks 4 or 8
+#endif
 
 // re-sweep the window of SWMI_CK_BLOCKS blocks that starts at block `wlo` of strip `s` into lds_tile.
 // DETECT: also append the window's cells equal to `maxv` to the pair's cell list; returns the new list length.
@@ -904,6 +896,17 @@ __device__ __forceinline__ uint32_t replay_dispatch(const TraceArgs &A, const Pa
         if (A.strict) return replay_window<R, false, true, MULTI, DETECT>(A, pd, n, m, refw, readw, G, s, wlo, lane, lds_tile, maxv, cnt_in, cells, ccap);
         else          return replay_window<R, false, false, MULTI, DETECT>(A, pd, n, m, refw, readw, G, s, wlo, lane, lds_tile, maxv, cnt_in, cells, ccap);
     }
+}
+
+// A pair swept by several wavefronts (column chunks, strips) reaches the mode-1 traceback with only its maximum combined:
+// a maximum of 0 is the degenerate case -- every one of the m*n cells ties (SmithWaterman.java:154,182-185).  (A pair swept
+// by one wavefront was marked by it.)  Returns true if `po` was completed here.
+__device__ __forceinline__ bool finish_pair(const TraceArgs &A, const PairDesc pd, PairOut &po) {
+    if (po.score > 0 || (po.flags & SWMI_F_DEGENERATE)) return false;
+    po.score = 0;
+    po.flags = SWMI_F_DEGENERATE;
+    po.n_cells = (uint64_t)A.reads[pd.read_id].len * A.refs[pd.ref_id].len;
+    return true;
 }
 
 // true for the pairs the full-featured mode-1 traceback handles: pure ACGT with int8 scores, the serial tie order
@@ -1455,6 +1458,7 @@ sw_traceback_winmax_kernel(const TraceArgs A) {
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const PairDesc pd = A.pairs[pair];
     PairOut po = A.out[pd.out_id];
+    if (finish_pair(A, pd, po) && wave == 0 && lane == 0) A.out[pd.out_id] = po;
     if (po.flags & SWMI_F_DEGENERATE) {                      // same decision in every wave: nobody waits at the barrier
         if (A.out_host && wave == 0 && lane == 0) A.out_host[pd.out_id] = po;
         return;
@@ -1579,7 +1583,8 @@ sw_detect_windows_kernel(const TraceArgs A) {
     }
     const uint32_t pair = lo, wloc = item - A.win_off[pair];
     const PairDesc pd = A.pairs[pair];
-    const PairOut po = A.out[pd.out_id];
+    PairOut po = A.out[pd.out_id];
+    if (finish_pair(A, pd, po) && wloc == 0u && lane == 0) A.out[pd.out_id] = po;     // (window 0's wave completes the record)
     if (po.flags & SWMI_F_DEGENERATE) return;
     const SeqDesc rd = A.refs[pd.ref_id];
     const SeqDesc qd = A.reads[pd.read_id];
@@ -1665,18 +1670,45 @@ sw_walk_items_kernel(const TraceArgs A) {
 // ------------------------------------------------------------------------------------------------
 // host-callable launchers (the runtime in swmi_api.cpp is plain C++)
 // ------------------------------------------------------------------------------------------------
+// Small launches: the dispatcher may stack several workgroups on one CU while other CUs stay empty (measured: 250
+// workgroups of the 67-VGPR column-chunk kernel ran two to a CU, each wave sharing its SIMD, 1.5x slower per step).  A
+// dynamic-LDS request nobody uses caps the workgroups a CU can hold at what an even spread needs, so the launch is dealt
+// over all 256 CUs.  SWMI_LDS_SPREAD=0 switches it off.
+static size_t spread_lds(uint32_t n_groups) {
+    static const int on = getenv("SWMI_LDS_SPREAD") ? atoi(getenv("SWMI_LDS_SPREAD")) : 1;
+    if (!on || n_groups == 0 || n_groups > 4u * 256u) return 0;
+    const uint32_t per_cu = (n_groups + 255u) / 256u;                      // workgroups a CU must take
+    const size_t lds = (size_t)(160u * 1024u) / per_cu;                    // per_cu fit, per_cu + 1 do not
+    return lds & ~(size_t)1023;
+}
+template <class K>
+static void allow_big_lds(K kernel) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
 extern "C" hipError_t swmi_launch_fill(const FillArgs *a, hipStream_t st) {
     if (a->n_pairs == 0) return hipSuccess;
+    static const bool attrs = [] {
+        allow_big_lds(sw_fill_kernel); allow_big_lds(sw_fill_score_kernel); allow_big_lds(sw_sweep_winmax_kernel);
+        allow_big_lds(sw_sweep_winmax_strips_kernel); allow_big_lds(sw_sweep_winmax_cols_kernel);
+        return true;
+    }();
+    (void)attrs;
     const dim3 grid((a->n_pairs + FILL_WAVES - 1) / FILL_WAVES), block(WAVE * FILL_WAVES);
-    if (a->mode == 0)      hipLaunchKernelGGL(sw_fill_kernel, grid, block, 0, st, *a);
+    const size_t lds = spread_lds(grid.x);
+    if (a->mode == 0)      hipLaunchKernelGGL(sw_fill_kernel, grid, block, lds, st, *a);
     else if (a->mode == 1) {
-        hipLaunchKernelGGL(sw_sweep_winmax_kernel, grid, block, 0, st, *a);
-        if (a->skip_multi && a->n_strip_items)
-            hipLaunchKernelGGL(sw_sweep_winmax_strips_kernel, dim3((a->n_strip_items + FILL_WAVES - 1) / FILL_WAVES), block, 0, st, *a);
-        if (a->n_col_items)
-            hipLaunchKernelGGL(sw_sweep_winmax_cols_kernel, dim3((a->n_col_items + FILL_WAVES - 1) / FILL_WAVES), block, 0, st, *a);
+        hipLaunchKernelGGL(sw_sweep_winmax_kernel, grid, block, a->n_col_items || a->n_strip_items ? 0 : lds, st, *a);
+        if (a->skip_multi && a->n_strip_items) {
+            const uint32_t g = (a->n_strip_items + FILL_WAVES - 1) / FILL_WAVES;
+            hipLaunchKernelGGL(sw_sweep_winmax_strips_kernel, dim3(g), block, spread_lds(g), st, *a);
+        }
+        if (a->n_col_items) {
+            const uint32_t g = (a->n_col_items + FILL_WAVES - 1) / FILL_WAVES;
+            hipLaunchKernelGGL(sw_sweep_winmax_cols_kernel, dim3(g), block, spread_lds(g), st, *a);
+        }
     }
-    else                   hipLaunchKernelGGL(sw_fill_score_kernel, grid, block, 0, st, *a);
+    else                   hipLaunchKernelGGL(sw_fill_score_kernel, grid, block, lds, st, *a);
     return hipGetLastError();
 }
 
