@@ -96,6 +96,10 @@ void        swmi_default_params(swmi_params *p);
  *                (default): split for launches of fewer than 64 pairs, and for batches of up to 256 pairs in which a sample
  *                of the pairs (aligned once, on the first run of a batch) averages >= auto_ties_x100 / 100 tied maxima
  *                per pair -- periodic references, the reference's own EngineerData sets.
+ * resident: -1 (default) pairs whose whole direction field fits 20 KB of LDS and whose reference is at most 8 x the read
+ *                (80 bp reads x 400 bp references, the reference's EngineerData shapes) are handled start to finish by one
+ *                wavefront -- two sweeps inside LDS, all alignments walked at once, one per lane; 0 never; 1 whenever the
+ *                field fits 40 KB.
  * Further knobs: spin_us (how long a run polls its stream before it blocks, default 2000); col_chunks (0 automatic,
  * 1 never, N > 1 force up to N column chunks per pair: a launch of few pairs with long references is swept by several
  * wavefronts per pair); debug_strip_spins / debug_reverse_strips (tests of the strip pipeline's give-up path). */
@@ -128,6 +132,8 @@ typedef struct swmi_timing {
     uint64_t dir_bytes;         /* direction-field bytes written                   */
     uint32_t strip_fallbacks;   /* launches repeated with the one-wavefront sweep after the strip pipeline gave up */
     uint32_t col_chunks;        /* column-chunk wavefronts the sweep of the run was split into (0: one per pair)    */
+    uint32_t resident_pairs;    /* pairs handled whole by one wavefront with the direction field in LDS             */
+    uint32_t pad;
 } swmi_timing;
 int  swmi_batch_timing(const swmi_batch *b, swmi_timing *t);
 /* The kernel pipeline (0, 1 or 2, see swmi_set_option "mode") the last run of the batch used. */

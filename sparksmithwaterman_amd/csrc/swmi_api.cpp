@@ -32,6 +32,7 @@
 extern "C" hipError_t swmi_launch_fill(const FillArgs *a, hipStream_t st);
 extern "C" hipError_t swmi_launch_traceback(const TraceArgs *a, hipStream_t st);
 extern "C" hipError_t swmi_launch_traceback_split(const TraceArgs *a, uint32_t n_windows, hipStream_t st);
+extern "C" hipError_t swmi_launch_resident(const TraceArgs *a, hipStream_t st);
 extern "C" hipError_t swmi_launch_encode(const uint8_t *raw, const uint64_t *raw_off, SeqDesc *desc, uint32_t *seqw,
                                          const uint8_t *lut, uint32_t n_seq, hipStream_t st);
 
@@ -120,6 +121,7 @@ struct swmi_ctx {
     uint32_t auto_ties_x100 = 300;          // automatic mode: mode 0 when a sampled pair has this many tied maxima (x 1/100) on average
     uint32_t col_chunks = 0;                // test knob: force this many column chunks per pair (0 = automatic)
     int tb_split = -1;                      // mode-1 traceback grain: -1 automatic, 0 one workgroup per pair, 1 one wavefront per window / alignment
+    int resident = -1;                      // small pairs handled by one wavefront with the direction field in LDS: -1 automatic, 0 never, 1 whenever it fits
     bool cell_cap_set = false;              // cell_cap given by the caller (otherwise small launches get longer lists)
     // swmi_batch_run_async: one run in flight on the context's own host thread
     std::thread worker;
@@ -138,7 +140,7 @@ struct HostAln {
     int32_t begin, end_i, end_j;
     uint32_t n_ops;
     uint64_t ops_at;        // index into swmi_batch::ops (dwords)
-    int64_t str_id = -1;    // index into the materialised-string cache
+    int64_t str_id = -1;    // >= 0 once the strings are built: offset of the reference-side string in swmi_batch::str_buf
 };
 
 struct PairRes {
@@ -175,6 +177,7 @@ struct swmi_batch {
     DevBuf d_strip_items, d_progress;       // mode 1: strip-per-wavefront sweep of long reads
     DevBuf d_col_items;                     // mode 1: column chunks of single-strip pairs
     DevBuf d_win_off, d_queue;              // split traceback: per-pair window offsets, walk-item queue
+    DevBuf d_res_items;                     // resident pairs of the launch
     bool views_built = false;               // some MapRef view of the last run was built (they are reset by the next run)
     bool tb_split_used = false;             // the last run used the split traceback
     bool acgt_known = false;                // ref_desc/read_desc[].acgt fetched back from the device (set there by the encode kernel)
@@ -202,6 +205,10 @@ struct swmi_batch {
         uint32_t max_path = 0, max_read = 0;
         size_t n_strip_items = 0, n_col_items = 0;
         uint64_t n_windows = 0;
+        size_t n_res = 0;
+        uint32_t res_lds_words = 0, res_ops_words = 0;
+        int resident_opt = -1;
+        bool exact = false;
         uint32_t col_chunks_opt = 0;
         bool reverse_strips = false;
     } prep;
@@ -213,7 +220,8 @@ struct swmi_batch {
     bool indexed = false;
     std::vector<HostAln> alns;              // grouped by pair, ordered as OptAlignments returns them
     std::vector<uint32_t> ops;              // concatenated op words of all records
-    std::vector<std::string> str_ref, str_read;   // materialised alignments
+    std::vector<char> str_buf;              // every alignment's two NUL-terminated strings, at fixed offsets (str_at)
+    std::vector<uint64_t> str_at;           // per alignment: offset of its reference-side string; the read side follows it
     // MapRef view cache
     std::vector<int8_t> ref_view_ready;
     std::vector<std::vector<SiteRef>> ref_sites;
@@ -329,6 +337,9 @@ extern "C" int swmi_set_option(swmi_ctx *ctx, const char *name, int64_t value) {
         ctx->dbg_strip_spins = (uint32_t)value;
     } else if (!strcmp(name, "debug_reverse_strips")) {
         ctx->dbg_reverse_strips = value != 0;
+    } else if (!strcmp(name, "resident")) {
+        if (value < -1 || value > 1) return fail(SWMI_ERR_INVALID, "resident must be -1 (automatic), 0 or 1");
+        ctx->resident = (int)value;
     } else if (!strcmp(name, "tb_split")) {
         if (value < -1 || value > 1) return fail(SWMI_ERR_INVALID, "tb_split must be -1 (automatic), 0 or 1");
         ctx->tb_split = (int)value;
@@ -413,7 +424,7 @@ extern "C" void swmi_batch_free(swmi_ctx *ctx, swmi_batch *b) {
     b->d_seqw.release(); b->d_refs.release(); b->d_reads.release(); b->d_pairs.release();
     b->d_dir.release(); b->d_seam.release(); b->d_result.release(); b->d_cells.release();
     b->d_cells_off.release(); b->d_cells_cap.release(); b->d_dbg.release(); b->d_dbg2.release();
-    b->d_strip_items.release(); b->d_progress.release(); b->d_col_items.release(); b->d_win_off.release(); b->d_queue.release();
+    b->d_strip_items.release(); b->d_progress.release(); b->d_col_items.release(); b->d_win_off.release(); b->d_queue.release(); b->d_res_items.release();
     b->h_result.release();
     delete b;
 }
@@ -546,14 +557,20 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
     size_t n_strip_items = 0, n_col_items = 0;
     uint64_t n_windows = 0;
     std::vector<uint32_t> win_off;           // split traceback: first window of every pair
+    std::vector<uint32_t> res_items;         // pairs handled whole by sw_resident_pairs_kernel
+    size_t n_res = 0;
+    uint32_t res_lds_words = 0, res_ops_words = 0;
+    const uint32_t res_cell_cap = 128;
     swmi_batch::Prep &pr = b->prep;
     const bool prepared = pr.valid && pr.lo == lo && pr.hi == hi && pr.work == (const void *)work.data() && pr.mode == b->eff_mode &&
                           memcmp(&pr.params, &b->params, sizeof(swmi_params)) == 0 && b->pairs_dev_ptr == b->d_pairs.p &&
                           b->pairs_on_device.size() == np * sizeof(PairDesc) && pr.col_chunks_opt == ctx->col_chunks &&
-                          pr.reverse_strips == (ctx->dbg_reverse_strips != 0);
+                          pr.reverse_strips == (ctx->dbg_reverse_strips != 0) && pr.resident_opt == ctx->resident &&
+                          pr.exact == (cells_exact != nullptr);
     if (prepared) {
         dir_words = pr.dir_words; seam_words = pr.seam_words; max_path = pr.max_path; max_read = pr.max_read;
         n_strip_items = pr.n_strip_items; n_col_items = pr.n_col_items; n_windows = pr.n_windows;
+        n_res = pr.n_res; res_lds_words = pr.res_lds_words; res_ops_words = pr.res_ops_words;
     } else {
     // Column chunks (swmi_device.h: ColItem): a launch of few pairs leaves most of the 1024 SIMDs idle while every pair is
     // one dependent chain of n + 63 steps.  A positive-score path spans at most m + match*m/|gap| columns (A <= m
@@ -562,7 +579,27 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
     const swmi_params &P = b->params;
     const bool cols_possible = b->eff_mode == 1 && P.match > 0 && P.gap < 0 && P.mismatch <= 0 &&
                                P.match <= 7 && P.mismatch >= -8 && (np <= 512 || ctx->col_chunks > 1) && ctx->col_chunks != 1;
-    if (cols_possible && !b->acgt_known) {
+    // Resident pairs (sw_resident_pairs_kernel): a pair whose whole direction field fits a wavefront's share of LDS -- and
+    // whose reference is short next to its read, so that the alignments cover most of the matrix anyway -- skips checkpoints
+    // and window re-sweeps altogether: one wavefront sweeps it twice inside LDS and walks ALL its alignments at once, one per
+    // lane.  (The exact-size re-run of pairs with more tied maxima than an LDS list holds takes the ordinary path.)
+    const bool res_possible = b->eff_mode == 1 && !cells_exact && ctx->resident != 0 && P.match <= 7 && P.match >= -8 &&
+                              P.mismatch >= -8 && P.mismatch <= 0 && P.gap <= 0;
+    auto res_need_words = [&](uint32_t m_, uint32_t n_, uint32_t &opw) -> uint64_t {
+        const uint32_t R_ = swmi_rows_per_lane(m_), lact = (m_ + R_ - 1) / R_;
+        const uint64_t nblk = ((uint64_t)n_ + lact - 1 + 15) / 16, n_ck = (nblk + SWMI_CK_BLOCKS - 1) / SWMI_CK_BLOCKS;
+        opw = (uint32_t)((path_bound(n_, m_, P) + 15) / 16 + 1);
+        return nblk * R_ * 64 + ((n_ck + 1) & ~1ull) + 2ull * res_cell_cap + 64ull * opw + (n_ + 3) / 4 + 1 + (m_ + 3) / 4 + 1 + 8;
+    };
+    bool res_maybe = false;
+    if (res_possible)
+        for (size_t k = 0; k < np && !res_maybe; k++) {
+            const uint32_t m_ = b->read_desc[work[lo + k].pair % n_reads].len, n_ = b->ref_desc[work[lo + k].pair / n_reads].len;
+            uint32_t opw;
+            res_maybe = m_ <= 64u * SWMI_RMAX && (ctx->resident == 1 || (uint64_t)n_ <= 8ull * m_) &&
+                        res_need_words(m_, n_, opw) * 4 <= (ctx->resident == 1 ? 40u : 20u) * 1024u;
+        }
+    if ((cols_possible || res_maybe) && !b->acgt_known) {
         // the fast-symbol flags are derived on the device by the encode kernel
         if (b->n_refs) HIP_TRY(hipMemcpy(b->ref_desc.data(), b->d_refs.p, b->n_refs * sizeof(SeqDesc), hipMemcpyDeviceToHost));
         if (b->n_reads) HIP_TRY(hipMemcpy(b->read_desc.data(), b->d_reads.p, b->n_reads * sizeof(SeqDesc), hipMemcpyDeviceToHost));
@@ -588,7 +625,17 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
             win_off[k] = (uint32_t)std::min<uint64_t>(n_windows, 0xFFFFFFFFu);
             n_windows += ((m_ + rps - 1) / rps) * ((wb + SWMI_CK_BLOCKS - 1u) / SWMI_CK_BLOCKS);
         }
-        if (b->eff_mode == 1 && m_ > 64u * SWMI_RMAX && strip_items.size() < (1u << 30)) {
+        uint32_t res_opw = 0;
+        const bool res_fit = res_maybe && m_ <= 64u * SWMI_RMAX && b->read_desc[d.read_id].acgt && b->ref_desc[d.ref_id].acgt &&
+                             (ctx->resident == 1 || (uint64_t)n_ <= 8ull * m_) &&
+                             res_need_words(m_, n_, res_opw) * 4 <= (ctx->resident == 1 ? 40u : 20u) * 1024u;
+        if (res_fit) {
+            d.pad = SWMI_PAD_RESIDENT;
+            res_items.push_back((uint32_t)k);
+            uint32_t opw;
+            res_lds_words = std::max<uint32_t>(res_lds_words, (uint32_t)res_need_words(m_, n_, opw));
+            res_ops_words = std::max(res_ops_words, opw);
+        } else if (b->eff_mode == 1 && m_ > 64u * SWMI_RMAX && strip_items.size() < (1u << 30)) {
             const uint32_t strips = (m_ + 64u * SWMI_RMAX - 1u) / (64u * SWMI_RMAX);
             d.pad = (uint32_t)strip_items.size();
             if (ctx->dbg_reverse_strips) for (uint32_t st = strips; st-- > 0;) strip_items.push_back(make_uint2((uint32_t)k, st));
@@ -626,6 +673,7 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
     }
     n_strip_items = strip_items.size();
     n_col_items = col_items.size();
+    n_res = res_items.size();
     if (b->eff_mode == 1) win_off[np] = (uint32_t)std::min<uint64_t>(n_windows, 0xFFFFFFFFu);
     }
     if (!prepared && b->eff_mode == 1) {
@@ -639,6 +687,11 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
         if ((rc = b->d_progress.reserve(strip_items.size() * sizeof(uint32_t)))) return rc;
         HIP_TRY(hipMemcpyAsync(b->d_strip_items.p, strip_items.data(), strip_items.size() * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));      // strip_items is a local
+    }
+    if (!prepared && !res_items.empty()) {
+        if ((rc = b->d_res_items.reserve(res_items.size() * sizeof(uint32_t)))) return rc;
+        HIP_TRY(hipMemcpyAsync(b->d_res_items.p, res_items.data(), res_items.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));      // res_items is a local
     }
     if (!prepared && !col_items.empty()) {
         if ((rc = b->d_col_items.reserve(col_items.size() * sizeof(ColItem)))) return rc;
@@ -660,6 +713,8 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
         pr.lo = lo; pr.hi = hi; pr.work = (const void *)work.data(); pr.params = b->params; pr.mode = b->eff_mode;
         pr.dir_words = dir_words; pr.seam_words = seam_words; pr.max_path = max_path; pr.max_read = max_read;
         pr.n_strip_items = n_strip_items; pr.n_col_items = n_col_items; pr.n_windows = n_windows;
+        pr.n_res = n_res; pr.res_lds_words = res_lds_words; pr.res_ops_words = res_ops_words;
+        pr.resident_opt = ctx->resident; pr.exact = cells_exact != nullptr;
         pr.col_chunks_opt = ctx->col_chunks; pr.reverse_strips = ctx->dbg_reverse_strips != 0;
     }
     if (seam_words) HIP_TRY(hipMemsetAsync(b->d_seam.p, 0, seam_words * 4, ctx->stream));
@@ -766,6 +821,8 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
         ta.out_host = nullptr;
         ta.ovf_host = nullptr;
         ta.win_off = nullptr; ta.q_count = nullptr; ta.q_items = nullptr; ta.q_cap = 0; ta.pad4 = 0;
+        ta.res_items = n_res ? b->d_res_items.as<uint32_t>() : nullptr;
+        ta.n_res = (uint32_t)n_res; ta.res_lds_words = res_lds_words; ta.res_cell_cap = res_cell_cap; ta.res_ops_words = res_ops_words;
         const bool zc = ctx->zero_copy != 0;
         if (zc) {
             // results land in pinned host memory while the kernel runs: [overflow word .. | PairOut x np | arena]
@@ -790,6 +847,8 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
             rs.launches++;
         }
         if (ctx->profiling) HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));     // end of the sweep = start of the traceback
+        if (n_res) HIP_TRY(swmi_launch_resident(&ta, ctx->stream));               // (timed with the traceback)
+        if (attempt == 0) b->timing.resident_pairs += (uint32_t)n_res;
         const bool split = rs.tb_split && b->eff_mode == 1 && n_windows < 0xFFFFFFFFull;
         if (split) {
             const uint64_t q_cap = std::min<uint64_t>(std::max<uint64_t>(cells_total, 1), 1ull << 24);
@@ -800,7 +859,7 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
             ta.q_cap = (uint32_t)q_cap;
             HIP_TRY(hipMemsetAsync(ta.q_count, 0, 4, ctx->stream));
             HIP_TRY(swmi_launch_traceback_split(&ta, (uint32_t)n_windows, ctx->stream));
-        } else {
+        } else if (n_res < np) {
             HIP_TRY(swmi_launch_traceback(&ta, ctx->stream));
         }
         if (ctx->profiling) HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
@@ -1036,9 +1095,11 @@ static int ensure_indexed(swmi_batch *b) {
             std::stable_sort(b->alns.begin() + pr.first, b->alns.begin() + pr.first + pr.count,
                              [](const HostAln &x, const HostAln &y) { return x.begin < y.begin; });
     }
-    b->str_ref.assign(run, std::string());
-    b->str_read.assign(run, std::string());
-    for (uint64_t k = 0; k < run; k++) b->alns[k].str_id = -1;
+    // one buffer for all strings (two mallocs per alignment cost more than filling them)
+    b->str_at.resize(run);
+    uint64_t chars = 0;
+    for (uint64_t k = 0; k < run; k++) { b->alns[k].str_id = -1; b->str_at[k] = chars; chars += 2ull * (b->alns[k].n_ops + 1); }
+    b->str_buf.resize(chars);
     b->indexed = true;
     return SWMI_OK;
 }
@@ -1066,7 +1127,7 @@ extern "C" int swmi_batch_run(swmi_ctx *ctx, swmi_batch *b, const swmi_params *p
     const uint32_t n_refs = b->n_refs, n_reads = b->n_reads;
     const uint64_t n_pairs = (uint64_t)n_refs * n_reads;
     b->pairs.assign(n_pairs, PairRes{});
-    b->alns.clear(); b->ops.clear(); b->str_ref.clear(); b->str_read.clear();
+    b->alns.clear(); b->ops.clear(); b->str_at.clear();
     b->raw.clear(); b->raw_chunks.clear(); b->indexed = false;
     if (b->views_built || b->ref_view_ready.size() != n_refs) {     // (a run nobody read MapRef views of leaves them as they are)
         b->ref_view_ready.assign(n_refs, 0);
@@ -1367,18 +1428,20 @@ static void materialise(swmi_batch *b, uint64_t pair, HostAln &a, uint64_t slot)
         ref = b->ref_bytes.data() + b->ref_off[r];
     }
     const uint8_t *read = b->read_bytes.data() + b->read_off[q];
-    std::string &sr = b->str_ref[slot], &sq = b->str_read[slot];
-    sr.resize(a.n_ops); sq.resize(a.n_ops);
-    int64_t i = a.end_i, j = a.end_j;     // 1-based cell of the op being emitted
+    char *sr = b->str_buf.data() + b->str_at[slot], *sq = sr + a.n_ops + 1;
+    sr[a.n_ops] = 0; sq[a.n_ops] = 0;
+    int64_t i = a.end_i, j = a.end_j;     // 1-based cell of the op being emitted (both >= 1 while ops remain)
     const uint32_t *ops = b->ops.data() + a.ops_at;
     for (uint32_t t = 0; t < a.n_ops; t++) {
         const uint32_t op = (ops[t >> 4] >> (2 * (t & 15))) & 3u;
         const uint32_t pos = a.n_ops - 1 - t;
-        if (op == SWMI_DIR_A)      { sr[pos] = (char)ref[j - 1]; sq[pos] = (char)read[i - 1]; i--; j--; }
-        else if (op == SWMI_DIR_I) { sr[pos] = '_';              sq[pos] = (char)read[i - 1]; i--; }
-        else                       { sr[pos] = (char)ref[j - 1]; sq[pos] = '_';               j--; }
+        // branch-free: gaps come at random places of a path (:388-406: alignment takes both, insertion the read's, deletion the reference's)
+        const bool use_ref = op != SWMI_DIR_I, use_read = op != SWMI_DIR_D;
+        sr[pos] = use_ref ? (char)ref[j - 1] : '_';
+        sq[pos] = use_read ? (char)read[i - 1] : '_';
+        j -= use_ref; i -= use_read;
     }
-    a.str_id = (int64_t)slot;
+    a.str_id = (int64_t)b->str_at[slot];
 }
 
 static const char EMPTY_STR[1] = {0};
@@ -1407,8 +1470,8 @@ extern "C" int swmi_pair_alignment(swmi_batch *b, uint64_t pair, uint64_t k,
     if (begin) *begin = a.begin;
     if (end_i) *end_i = a.end_i;
     if (end_j) *end_j = a.end_j;
-    if (ref_aln) *ref_aln = b->str_ref[a.str_id].c_str();
-    if (read_aln) *read_aln = b->str_read[a.str_id].c_str();
+    if (ref_aln) *ref_aln = b->str_buf.data() + a.str_id;
+    if (read_aln) *read_aln = b->str_buf.data() + a.str_id + a.n_ops + 1;
     if (len) *len = a.n_ops;
     return SWMI_OK;
 }

@@ -63,6 +63,8 @@ struct PairDesc {
 
 // PairDesc.pad of a single-strip pair whose sweep is split into column chunks (mode 1): this flag + the number of chunks
 #define SWMI_PAD_COLS 0x80000000u
+// PairDesc.pad of a pair handled start to finish by sw_resident_pairs_kernel (mode 1, small pairs): every other kernel skips it
+#define SWMI_PAD_RESIDENT 0x40000000u
 
 // One column chunk of a pair's mode-1 sweep (sw_sweep_winmax_cols_kernel): the wavefront starts a fresh sweep at
 // reference column col0 + 1 (col0 a multiple of 32) -- far enough to the left that every cell from checkpoint window
@@ -160,6 +162,12 @@ struct TraceArgs {
     uint4          *q_items;     // {pair index of the launch, i, j, 0}
     uint32_t        q_cap;
     uint32_t        pad4;
+    // resident pairs (sw_resident_pairs_kernel): pairs whose whole direction field fits a wavefront's share of LDS
+    const uint32_t *res_items;   // indices into pairs[]
+    uint32_t        n_res;
+    uint32_t        res_lds_words;   // LDS dwords per wavefront (the largest resident pair of the launch)
+    uint32_t        res_cell_cap;    // maximum cells a resident pair may list in LDS (more: SWMI_F_CELL_OVF, re-run by the ordinary path)
+    uint32_t        res_ops_words;   // dwords of packed ops a lane can stage (the longest possible path of the launch)
 };
 
 #define SWMI_RANK_BY_CELL 0xFFFFFFFFu   // AlnRec.rank of the split traceback: the host orders a pair's records by (end_i, end_j)

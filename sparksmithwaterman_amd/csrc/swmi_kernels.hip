@@ -729,6 +729,7 @@ __device__ __forceinline__ void fill_entry(const FillArgs &A) {
     const uint32_t lane = threadIdx.x & 63u;
     if (pair == 0 && lane == 0 && A.hdr) { A.hdr->used_words = 0; A.hdr->n_records = 0; }   // arena reset for the traceback kernel that follows
     const PairDesc pd = A.pairs[pair];
+    if (MODE == SWMI_MODE_WINMAX && (pd.pad & SWMI_PAD_RESIDENT)) return;            // sw_resident_pairs_kernel does the whole pair
     const SeqDesc rd = A.refs[pd.ref_id];
     const SeqDesc qd = A.reads[pd.read_id];
     if (MODE == SWMI_MODE_WINMAX && A.skip_multi && qd.len > WAVE * SWMI_RMAX) {
@@ -1457,6 +1458,7 @@ sw_traceback_winmax_kernel(const TraceArgs A) {
     // (rotating the walker role over the hardware waves, in case wave w always landed on SIMD w, changes nothing)
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const PairDesc pd = A.pairs[pair];
+    if (pd.pad & SWMI_PAD_RESIDENT) return;                  // done by sw_resident_pairs_kernel (same decision in every wave)
     PairOut po = A.out[pd.out_id];
     if (finish_pair(A, pd, po) && wave == 0 && lane == 0) A.out[pd.out_id] = po;
     if (po.flags & SWMI_F_DEGENERATE) {                      // same decision in every wave: nobody waits at the barrier
@@ -1583,6 +1585,7 @@ sw_detect_windows_kernel(const TraceArgs A) {
     }
     const uint32_t pair = lo, wloc = item - A.win_off[pair];
     const PairDesc pd = A.pairs[pair];
+    if (pd.pad & SWMI_PAD_RESIDENT) return;                  // done by sw_resident_pairs_kernel
     PairOut po = A.out[pd.out_id];
     if (finish_pair(A, pd, po) && wloc == 0u && lane == 0) A.out[pd.out_id] = po;     // (window 0's wave completes the record)
     if (po.flags & SWMI_F_DEGENERATE) return;
@@ -1665,6 +1668,247 @@ sw_walk_items_kernel(const TraceArgs A) {
         else             traceback_pair<4, 1, false>(A, pd, po, lane, 0u, 1u, lds, tile, nullptr, 1u, 0xFFFFFFFFu, false, &item);
         WAVE_SYNC();
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// resident pairs (mode 1): a pair whose WHOLE 2-bit direction field fits a wavefront's share of LDS -- the reference's
+// own benchmark shapes, 80 bp reads against 400 bp references (EngineerData.java:51-224) -- is handled start to finish
+// by one wavefront, with nothing but its result leaving the CU:
+//   A  score sweep (the 3-VALU cells of sweep_fast), one maximum per 32-step window kept in LDS -> the pair's maximum;
+//   B  second sweep with direction bits (the same cell stream the replay uses) into LDS, with the cell test switched on
+//      in the windows whose maximum equals the pair's -> the tied maximum cells, listed in LDS;
+//   C  ALL alignments walked at once, one LANE each: a lane chases its own path through the field in LDS (three LDS
+//      reads and ~35 VALU per step for up to 64 alignments together), tracking the score like SmithWaterman.java:380-409,
+//      packing its ops into its own scratch row; the wave then reserves arena space with one atomicAdd and the lanes
+//      copy their records out.  Periodic references give every pair a handful of alignments: they cost one walk, not five.
+// No checkpoints, no HBM workspace.  The host orders a pair's records by cell (SWMI_RANK_BY_CELL).
+// LDS per wavefront (dwords): field [wblocks*R*64] | window maxima [n_ck] | cells [2*cell_cap] | ops [64*ops_words] |
+//                             reference codes [(n+3)/4+1] | read codes [(m+3)/4+1]
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_scan_add_u32(uint32_t v) {          // inclusive prefix sum over the 64 lanes (DPP)
+#define SWMI_DPP_ADD(ctrl, rmask, bmask)                                                     \
+    { const uint32_t o_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rmask, bmask, true); v += o_; }
+    SWMI_DPP_ADD(0x111, 0xf, 0xf)   // row_shr:1
+    SWMI_DPP_ADD(0x112, 0xf, 0xf)   // row_shr:2
+    SWMI_DPP_ADD(0x114, 0xf, 0xf)   // row_shr:4
+    SWMI_DPP_ADD(0x118, 0xf, 0xf)   // row_shr:8  -> inclusive scan inside every row of 16
+    SWMI_DPP_ADD(0x142, 0xa, 0xf)   // row_bcast:15 -> rows 1 and 3 add the total of the row before
+    SWMI_DPP_ADD(0x143, 0xc, 0xf)   // row_bcast:31 -> rows 2 and 3 add the total of rows 0-1
+#undef SWMI_DPP_ADD
+    return v;
+}
+
+template <int R, bool STRICT>
+__device__ __forceinline__ void resident_pair(const TraceArgs &A, const PairDesc pd, const uint32_t lane, uint32_t *__restrict__ lds) {
+    const SeqDesc rd = A.refs[pd.ref_id];
+    const SeqDesc qd = A.reads[pd.read_id];
+    const uint32_t n = rd.len, m = qd.len;
+    const uint32_t *__restrict__ refw = A.seqw + rd.boff;
+    const uint32_t *__restrict__ readw = A.seqw + qd.boff;
+    const uint32_t lact = (m + R - 1) / R;                                  // one strip: m <= 64 * R
+    const uint32_t lane_eff = lane < lact ? lane : 0x40000000u;
+    const uint32_t T = n + lact - 1, nblk = (T + 15u) / 16u, n_ck = (nblk + SWMI_CK_BLOCKS - 1u) / SWMI_CK_BLOCKS;
+    uint32_t *field = lds;                                                  // [nblk][R][64]
+    uint32_t *wmaxs = field + nblk * R * WAVE;
+    uint2 *cells = reinterpret_cast<uint2 *>(wmaxs + ((n_ck + 1u) & ~1u));
+    uint32_t *opsb = reinterpret_cast<uint32_t *>(cells + A.res_cell_cap);
+    uint32_t *refc = opsb + WAVE * A.res_ops_words;
+    uint32_t *readc = refc + (n + 3u) / 4u + 1u;
+    for (uint32_t w = lane; w < (n + 3u) / 4u; w += WAVE) refc[w] = refw[w];
+    for (uint32_t w = lane; w < (m + 3u) / 4u; w += WAVE) readc[w] = readw[w];
+    const uint4 *__restrict__ refq = reinterpret_cast<const uint4 *>(refw);
+
+    // ---- A: scores only ---------------------------------------------------------------------------------------------
+    int pair_max = 0;
+    {
+        const uint32_t gm = (uint32_t)(-(int64_t)A.gap);
+        const int one = 1;
+        SweepState<R> S;
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const uint32_t row = lane * R + k;
+            uint32_t p = (uint32_t)(A.mismatch & 0xF) * 0x11111111u;
+            if (row < m) {
+                const uint32_t c = seq_code(readw, row);
+                p = (p & ~(0xFu << c)) | ((uint32_t)(A.match & 0xF) << c);
+            }
+            S.q[k] = (int)p;
+            S.h[k] = 0; S.g[k] = 0; S.hp[k] = 0;
+        }
+        S.lmax = -1;
+        uint4 wnext = refq[0];
+        S.rby = 0;
+        S.rbx = wave_shr1((int)(1u << (wnext.x & 31u)), 0);
+        for (uint32_t tb = 0; tb < nblk; ++tb) {
+            const uint4 w = wnext;
+            wnext = refq[tb + 1];
+            if ((tb % SWMI_CK_BLOCKS) == 0u && tb > 0u) {
+                const int wm = wave_max_i32(lane < lact ? S.lmax : -1);
+                if (lane == 0) wmaxs[tb / SWMI_CK_BLOCKS - 1u] = (uint32_t)wm;
+                pair_max = pair_max > wm ? pair_max : wm;
+                S.lmax = -1;
+            }
+            const uint32_t t0 = 16u * tb;
+#ifndef SWMI_NO_ASM
+            if (t0 + 15u < n) {
+                SweepStep4Asm<R>::run(S.h, S.g, S.hp, S.q, S.rbx, S.rby, w.x, w.y, one, gm, S.lmax);
+                SweepStep4Asm<R>::run(S.h, S.g, S.hp, S.q, S.rbx, S.rby, w.y, w.z, one, gm, S.lmax);
+                SweepStep4Asm<R>::run(S.h, S.g, S.hp, S.q, S.rbx, S.rby, w.z, w.w, one, gm, S.lmax);
+                SweepStep4Asm<R>::run(S.h, S.g, S.hp, S.q, S.rbx, S.rby, w.w, wnext.x, one, gm, S.lmax);
+            } else
+#endif
+            {
+#pragma unroll
+                for (uint32_t s = 0; s < 16; ++s) {
+                    const uint32_t s1 = s + 1u;
+                    const uint32_t wf = s1 < 4 ? w.x : s1 < 8 ? w.y : s1 < 12 ? w.z : s1 < 16 ? w.w : wnext.x;
+                    const uint32_t code = (wf >> (8u * (s1 & 3u))) & 0xFFu;
+                    const bool in_range = (t0 + s - lane_eff) < n;
+                    if (s & 1u) sweep_step_ref<R>(S.g, S.h, S.hp, S.q, S.rby, S.rbx, code, gm, S.lmax, in_range);
+                    else        sweep_step_ref<R>(S.h, S.g, S.hp, S.q, S.rbx, S.rby, code, gm, S.lmax, in_range);
+                }
+            }
+        }
+        const int wm = wave_max_i32(lane < lact ? S.lmax : -1);
+        if (lane == 0) wmaxs[(nblk - 1u) / SWMI_CK_BLOCKS] = (uint32_t)wm;
+        pair_max = pair_max > wm ? pair_max : wm;
+    }
+    PairOut po;
+    if (pair_max <= 0) {                                                   // every cell ties at 0: SmithWaterman.java:154,182-185
+        po.score = 0; po.flags = SWMI_F_DEGENERATE; po.n_cells = (uint64_t)m * n;
+        if (lane == 0) { A.out[pd.out_id] = po; if (A.out_host) A.out_host[pd.out_id] = po; }
+        return;
+    }
+    WAVE_SYNC();
+
+    // ---- B: direction bits into LDS, the cells equal to the maximum listed on the way ----------------------------------
+    uint32_t ncell;
+    {
+        FillState<R> S;
+        S.thr = pair_max; S.cnt = 0; S.ev_prev = 0; S.events = 0; S.dbg_skip = false; S.lmax = -1;
+        setup_rows<R, true>(S, readw, lane * R, m, A.match, A.mismatch);
+        uint4 wnext = refq[0];
+        for (uint32_t tb = 0; tb < nblk; ++tb) {
+            const uint4 w = wnext;
+            wnext = refq[tb + 1];
+            const uint32_t t0 = 16u * tb;
+            const bool steady = (t0 + 1u >= lact) && (t0 + 15u < n);
+            const bool hot = (int)wmaxs[tb / SWMI_CK_BLOCKS] == pair_max;       // (wave-uniform: an LDS word)
+            if (hot) {
+                if (steady) fill_block16<R, true, STRICT, false, false, SWMI_MODE_DETECT>(S, w, t0, lane, lane_eff, n, m, lane * R, A.gap, A.match, A.mismatch,
+                                                                                          0, false, false, nullptr, cells, A.res_cell_cap);
+                else        fill_block16<R, true, STRICT, false, true, SWMI_MODE_DETECT>(S, w, t0, lane, lane_eff, n, m, lane * R, A.gap, A.match, A.mismatch,
+                                                                                         0, false, false, nullptr, cells, A.res_cell_cap);
+            } else {
+                if (steady) fill_block16<R, true, STRICT, false, false, SWMI_MODE_REPLAY>(S, w, t0, lane, lane_eff, n, m, lane * R, A.gap, A.match, A.mismatch,
+                                                                                          0, false, false, nullptr, nullptr, 0u);
+                else        fill_block16<R, true, STRICT, false, true, SWMI_MODE_REPLAY>(S, w, t0, lane, lane_eff, n, m, lane * R, A.gap, A.match, A.mismatch,
+                                                                                         0, false, false, nullptr, nullptr, 0u);
+            }
+            const int miss = (int)(t0 + 15u) - ((int)(lane + n) - 1);           // a lane past its last column still owes the missing shifts
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                uint32_t v = S.acc[k];
+                if (miss > 0 && miss < 16) v <<= 2 * miss;
+                field[(tb * R + k) * WAVE + lane] = v;
+            }
+        }
+        ncell = S.cnt;
+    }
+    po.score = pair_max; po.flags = ncell > A.res_cell_cap ? SWMI_F_CELL_OVF : 0u; po.n_cells = ncell;
+    if (lane == 0) { A.out[pd.out_id] = po; if (A.out_host) A.out_host[pd.out_id] = po; }
+    if (ncell > A.res_cell_cap || ncell == 0u) return;            // (too many: the host re-runs the pair through the ordinary path)
+    WAVE_SYNC();
+
+    // ---- C: one lane per alignment ----------------------------------------------------------------------------------
+    const uint8_t *ref_b = reinterpret_cast<const uint8_t *>(refc);
+    const uint8_t *read_b = reinterpret_cast<const uint8_t *>(readc);
+    const uint32_t umat = (uint32_t)A.match, umis = (uint32_t)A.mismatch, ugap = (uint32_t)A.gap;
+    const uint32_t max_ops = 16u * A.res_ops_words;
+    for (uint32_t base = 0; base < ncell; base += WAVE) {
+        const bool mine = base + lane < ncell;
+        const uint2 c0 = mine ? cells[base + lane] : make_uint2(0u, 0u);
+        uint32_t i = c0.x, j = c0.y, score = (uint32_t)pair_max, nops = 0, cur = 0;
+        int begin = 0;
+        bool active = mine;
+        uint32_t *my_ops = opsb + lane * A.res_ops_words;
+        while (BALLOT(active)) {
+            if (active) {
+                const uint32_t rho = i - 1u, l = rho / R, k = rho - l * R;
+                const uint32_t t = j - 1u + l;
+                const uint32_t dw = field[((t >> 4) * R + k) * WAVE + l];
+                const uint32_t rc = ref_b[j - 1u], qc = read_b[i - 1u];
+                const uint32_t d = (dw >> (2u * (15u - (t & 15u)))) & 3u;
+                const bool isA = (d & 1u) != 0u, isI = d == 2u;
+                begin = (int)j;                                                  // SmithWaterman.java:383
+                score -= isA ? (rc == qc ? umat : umis) : ugap;                  // :388-406, H(pred) = H - delta
+                const uint32_t op = isA ? SWMI_DIR_A : (isI ? SWMI_DIR_I : SWMI_DIR_D);
+                cur |= op << (2u * (nops & 15u));
+                ++nops;
+                if ((nops & 15u) == 0u) { if (nops <= max_ops) my_ops[(nops >> 4) - 1u] = cur; cur = 0; }
+                i -= (isA || isI) ? 1u : 0u;
+                j -= (isA || !isI) ? 1u : 0u;
+                active = (int)score > 0 && i != 0u && j != 0u;                   // `while (score > 0)` :380
+            }
+        }
+        if ((nops & 15u) != 0u && nops <= max_ops) my_ops[nops >> 4] = cur;
+        WAVE_SYNC();
+        // records: header + packed ops, contiguous for the whole wave
+        const uint32_t opw = (nops + 15u) / 16u;
+        const uint32_t words = mine ? SWMI_ALNREC_WORDS + opw : 0u;
+        const uint32_t incl = wave_scan_add_u32(words);
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        unsigned long long off = 0;
+        if (lane == 0) off = atomicAdd(&A.hdr->used_words, (unsigned long long)total);
+        off = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(off >> 32)) << 32) |
+              (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)off);
+        const bool too_long = BALLOT(mine && nops > max_ops) != 0ull;
+        if (off + total <= A.arena_cap_words && !too_long) {
+            if (mine) {
+                uint32_t *dst = A.arena + off + (incl - words);
+                dst[0] = pd.out_id; dst[1] = SWMI_RANK_BY_CELL; dst[2] = (uint32_t)begin;
+                dst[3] = c0.x; dst[4] = c0.y; dst[5] = nops;
+                for (uint32_t w = 0; w < opw; ++w) dst[SWMI_ALNREC_WORDS + w] = my_ops[w];
+            }
+        } else if (lane == 0) {
+            atomicOr(&A.out[pd.out_id].flags, SWMI_F_ARENA_OVF);
+            if (A.ovf_host) *A.ovf_host = 1u;
+        }
+        WAVE_SYNC();
+    }
+}
+
+extern "C" __global__ void __launch_bounds__(WAVE * FILL_WAVES)
+sw_resident_pairs_kernel(const TraceArgs A) {
+    extern __shared__ uint32_t rp_lds[];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t item = blockIdx.x * FILL_WAVES + wave;
+    if (item >= A.n_res) return;
+    // (the arena header was reset by sw_sweep_winmax_kernel, one launch earlier; the traceback kernels append after this one)
+    const PairDesc pd = A.pairs[A.res_items[item]];
+    uint32_t *lds = rp_lds + wave * A.res_lds_words;
+    const uint32_t R = swmi_rows_per_lane(A.reads[pd.read_id].len);
+    if (A.strict) {
+        if (R == 1)      resident_pair<1, true>(A, pd, lane, lds);
+        else if (R == 2) resident_pair<2, true>(A, pd, lane, lds);
+        else if (R == 3) resident_pair<3, true>(A, pd, lane, lds);
+        else             resident_pair<4, true>(A, pd, lane, lds);
+    } else {
+        if (R == 1)      resident_pair<1, false>(A, pd, lane, lds);
+        else if (R == 2) resident_pair<2, false>(A, pd, lane, lds);
+        else if (R == 3) resident_pair<3, false>(A, pd, lane, lds);
+        else             resident_pair<4, false>(A, pd, lane, lds);
+    }
+}
+
+extern "C" hipError_t swmi_launch_resident(const TraceArgs *a, hipStream_t st) {
+    if (a->n_res == 0) return hipSuccess;
+    static const bool attr = [] { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(sw_resident_pairs_kernel),
+                                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); return true; }();
+    (void)attr;
+    hipLaunchKernelGGL(sw_resident_pairs_kernel, dim3((a->n_res + FILL_WAVES - 1) / FILL_WAVES), dim3(WAVE * FILL_WAVES),
+                       (size_t)FILL_WAVES * a->res_lds_words * sizeof(uint32_t), st, *a);
+    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------

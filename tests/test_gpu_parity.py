@@ -19,17 +19,20 @@ READ_80 = "AATTTTAGTCTCTCCCTACCCTTTTGGACAGAGCTTCCTGTCCTCTCATTTCACAGGTTATGCAACAGA
 READ_20 = "ACTGACTGACTGACTGACTG"   # EngineerData.java:29
 
 
-@pytest.fixture(scope="module", params=[(1, 1, 0), (2, 1, 0), (0, 1, 0), (1, 0, 0), (-1, 1, -1), (1, 1, 1), (1, 0, 1)],
+@pytest.fixture(scope="module", params=[(1, 1, 0, 0), (2, 1, 0, 0), (0, 1, 0, 0), (1, 0, 0, 0), (-1, 1, -1, -1), (1, 1, 1, 0), (1, 0, 1, 0),
+                                        (1, 1, 0, 1), (1, 0, -1, 1)],
                 ids=["mode1-winmax", "mode2-events", "mode0-field", "mode1-d2h-copy", "automatic", "mode1-split-traceback",
-                     "mode1-split-d2h-copy"])
+                     "mode1-split-d2h-copy", "mode1-resident", "mode1-resident-d2h-copy"])
 def ctx(request):
     """Every kernel pipeline (include/swmi.h, swmi_set_option "mode"), results written straight to pinned host
     memory or fetched by a copy, the mode-1 traceback with one workgroup per pair or split per window / alignment
-    (option "tb_split"; -1 lets the library choose)."""
+    (option "tb_split"), small pairs handled whole by one wavefront with the direction field in LDS (option "resident":
+    0 never, 1 wherever it fits); -1 lets the library choose."""
     c = sw.Context(0)
     c.set_option("mode", request.param[0])
     c.set_option("zero_copy", request.param[1])
     c.set_option("tb_split", request.param[2])
+    c.set_option("resident", request.param[3])
     yield c
     c.close()
 
@@ -385,3 +388,33 @@ def test_config3_shape_many_reads_totals_winners_topk(ctx):
         assert int(totals[r]) == t
         assert b.ref_match_sites(r) == sites
     b.free()
+
+
+def test_resident_pairs_engineerdata_shapes(ctx):
+    """The reference's own benchmark shapes (EngineerData.java:51-224): 80 bp reads against 400 bp periodic references, one
+    tied maximum per period.  In mode 1 such pairs are handled by sw_resident_pairs_kernel (two sweeps inside LDS, every
+    alignment walked by its own lane); checked in full against the oracle, with a batch large enough to fill the chip, more
+    tied maxima than lanes in one pair, and reads that do not match at all."""
+    rng = random.Random(31)
+    refs = [REF * 5, REF * 5, (REF * 5)[3:393], REF[::-1] * 4, "".join(rng.choice("ACGT") for _ in range(400)), "G" * 300]
+    reads = [READ_80, REF[7:87], READ_20, REF[40:80] + REF[:40], "ACGT" * 10, "T" * 30]
+    check_batch(ctx, refs, reads)
+    check_batch(ctx, refs[:3], reads[:3], scores=(1, -1, -1), tie=1)
+    b = ctx.upload(refs, reads).run()
+    if b.pipeline_mode() == 1 and ctx_resident_on(ctx):
+        assert b.timing().resident_pairs > 0
+    b.free()
+    many = [REF * 5] * 3000 + [REF[::-1] * 5] * 100
+    b = ctx.upload(many, [READ_80, READ_20]).run()
+    sc, na = b.pair_results()
+    want = {}
+    for k in (0, 1, 2999, 3000, 3099):
+        for q, read in enumerate((READ_80, READ_20)):
+            es, ea = want.setdefault((many[k], read), orc.opt_alignments((many[k], read)))
+            assert int(sc[k * 2 + q]) == es and b.alignments(k * 2 + q) == ea
+    assert len(set(int(x) for x in sc[0:6000:2])) == 1 and len(set(int(x) for x in na[0:6000:2])) == 1
+    b.free()
+
+
+def ctx_resident_on(ctx):
+    return True
