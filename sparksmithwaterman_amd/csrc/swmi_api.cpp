@@ -583,8 +583,10 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
     // whose reference is short next to its read, so that the alignments cover most of the matrix anyway -- skips checkpoints
     // and window re-sweeps altogether: one wavefront sweeps it twice inside LDS and walks ALL its alignments at once, one per
     // lane.  (The exact-size re-run of pairs with more tied maxima than an LDS list holds takes the ordinary path.)
-    const bool res_possible = b->eff_mode == 1 && !cells_exact && ctx->resident != 0 && P.match <= 7 && P.match >= -8 &&
-                              P.mismatch >= -8 && P.mismatch <= 0 && P.gap <= 0;
+    // (measured, profiles/r02/sweeps_*.md: below ~300 pairs the launch is latency-bound and the split traceback, which
+    // spreads a pair's windows and alignments over many wavefronts, is faster)
+    const bool res_possible = b->eff_mode == 1 && !cells_exact && ctx->resident != 0 && (ctx->resident == 1 || np >= 256) &&
+                              P.match <= 7 && P.match >= -8 && P.mismatch >= -8 && P.mismatch <= 0 && P.gap <= 0;
     auto res_need_words = [&](uint32_t m_, uint32_t n_, uint32_t &opw) -> uint64_t {
         const uint32_t R_ = swmi_rows_per_lane(m_), lact = (m_ + R_ - 1) / R_;
         const uint64_t nblk = ((uint64_t)n_ + lact - 1 + 15) / 16, n_ck = (nblk + SWMI_CK_BLOCKS - 1) / SWMI_CK_BLOCKS;
@@ -674,6 +676,19 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
     n_strip_items = strip_items.size();
     n_col_items = col_items.size();
     n_res = res_items.size();
+    // the kernel lays every wavefront's LDS out with the launch-wide ops_words: size the share for that
+    res_lds_words = 0;
+    for (uint32_t k : res_items) {
+        uint32_t opw;
+        const uint32_t m_ = b->read_desc[pd[k].read_id].len, n_ = b->ref_desc[pd[k].ref_id].len;
+        const uint64_t own = res_need_words(m_, n_, opw);
+        res_lds_words = std::max<uint32_t>(res_lds_words, (uint32_t)(own + 64ull * (res_ops_words - opw)));
+    }
+    if (16ull * res_lds_words > 160ull * 1024) {          // four such shares do not fit a CU's LDS: the ordinary path for all of them
+        for (uint32_t k : res_items) pd[k].pad = 0;
+        res_items.clear();
+        n_res = 0; res_lds_words = 0; res_ops_words = 0;
+    }
     if (b->eff_mode == 1) win_off[np] = (uint32_t)std::min<uint64_t>(n_windows, 0xFFFFFFFFu);
     }
     if (!prepared && b->eff_mode == 1) {
@@ -849,7 +864,8 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
         if (ctx->profiling) HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));     // end of the sweep = start of the traceback
         if (n_res) HIP_TRY(swmi_launch_resident(&ta, ctx->stream));               // (timed with the traceback)
         if (attempt == 0) b->timing.resident_pairs += (uint32_t)n_res;
-        const bool split = rs.tb_split && b->eff_mode == 1 && n_windows < 0xFFFFFFFFull;
+        // (the exact-size re-run of pairs whose lists overflowed takes one workgroup per pair: its lists have no per-window cap)
+        const bool split = rs.tb_split && !cells_exact && b->eff_mode == 1 && n_windows < 0xFFFFFFFFull;
         if (split) {
             const uint64_t q_cap = std::min<uint64_t>(std::max<uint64_t>(cells_total, 1), 1ull << 24);
             if ((rc = b->d_queue.reserve(256 + q_cap * sizeof(uint4)))) return rc;
@@ -1486,14 +1502,32 @@ extern "C" int swmi_batch_materialise_all(swmi_batch *b, uint64_t *n_alignments,
     uint64_t na = 0, nc = 0;
     const uint64_t np = (uint64_t)b->n_refs * b->n_reads;
     for (uint64_t pair = 0; pair < np; pair++) {
-        PairRes &pr = b->pairs[pair];
+        const PairRes &pr = b->pairs[pair];
         if (pr.flags & SWMI_PAIR_DEGENERATE) { na += pr.n_cells; continue; }     // (0, "", "") each: nothing to build
-        for (uint64_t k = 0; k < pr.count; k++) {
-            HostAln &a = b->alns[pr.first + k];
-            if (a.str_id < 0) materialise(b, pair, a, pr.first + k);
-            nc += 2ull * a.n_ops;
-        }
+        for (uint64_t k = 0; k < pr.count; k++) nc += 2ull * b->alns[pr.first + k].n_ops;
         na += pr.count;
+    }
+    // every string has its own place in str_buf: pairs are built independently, by a few threads when there is enough to do
+    // (streamed chunks re-read reference bytes through a cache that is not thread-safe: one thread there)
+    auto build = [b](uint64_t lo, uint64_t hi) {
+        for (uint64_t pair = lo; pair < hi; pair++) {
+            PairRes &pr = b->pairs[pair];
+            if (pr.flags & SWMI_PAIR_DEGENERATE) continue;
+            for (uint64_t k = 0; k < pr.count; k++) {
+                HostAln &a = b->alns[pr.first + k];
+                if (a.str_id < 0) materialise(b, pair, a, pr.first + k);
+            }
+        }
+    };
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const unsigned nt = (b->src_map || nc < 200000) ? 1u : std::min<unsigned>({4u, hw, (unsigned)(nc / 100000)});
+    if (nt <= 1) {
+        build(0, np);
+    } else {
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < nt; t++) th.emplace_back(build, np * t / nt, np * (t + 1) / nt);
+        build(0, np / nt);
+        for (auto &x : th) x.join();
     }
     if (n_alignments) *n_alignments = na;
     if (n_chars) *n_chars = nc;

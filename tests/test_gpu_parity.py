@@ -33,6 +33,7 @@ def ctx(request):
     c.set_option("zero_copy", request.param[1])
     c.set_option("tb_split", request.param[2])
     c.set_option("resident", request.param[3])
+    c.test_resident = request.param[3]
     yield c
     c.close()
 
@@ -401,11 +402,13 @@ def test_resident_pairs_engineerdata_shapes(ctx):
     check_batch(ctx, refs, reads)
     check_batch(ctx, refs[:3], reads[:3], scores=(1, -1, -1), tie=1)
     b = ctx.upload(refs, reads).run()
-    if b.pipeline_mode() == 1 and ctx_resident_on(ctx):
+    if b.pipeline_mode() == 1 and ctx.test_resident == 1:
         assert b.timing().resident_pairs > 0
     b.free()
     many = [REF * 5] * 3000 + [REF[::-1] * 5] * 100
     b = ctx.upload(many, [READ_80, READ_20]).run()
+    if b.pipeline_mode() == 1 and ctx.test_resident != 0:
+        assert b.timing().resident_pairs >= 3100           # (automatic: launches of at least 256 pairs)
     sc, na = b.pair_results()
     want = {}
     for k in (0, 1, 2999, 3000, 3099):
@@ -414,7 +417,3 @@ def test_resident_pairs_engineerdata_shapes(ctx):
             assert int(sc[k * 2 + q]) == es and b.alignments(k * 2 + q) == ea
     assert len(set(int(x) for x in sc[0:6000:2])) == 1 and len(set(int(x) for x in na[0:6000:2])) == 1
     b.free()
-
-
-def ctx_resident_on(ctx):
-    return True
