@@ -32,7 +32,7 @@
 extern "C" hipError_t swmi_launch_fill(const FillArgs *a, hipStream_t st);
 extern "C" hipError_t swmi_launch_traceback(const TraceArgs *a, hipStream_t st);
 extern "C" hipError_t swmi_launch_traceback_split(const TraceArgs *a, uint32_t n_windows, hipStream_t st);
-extern "C" hipError_t swmi_launch_resident(const TraceArgs *a, hipStream_t st);
+extern "C" hipError_t swmi_launch_resident(const TraceArgs *a, const ResidentArgs *x, hipStream_t st);
 extern "C" hipError_t swmi_launch_encode(const uint8_t *raw, const uint64_t *raw_off, SeqDesc *desc, uint32_t *seqw,
                                          const uint8_t *lut, uint32_t n_seq, hipStream_t st);
 
@@ -836,8 +836,9 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
         ta.out_host = nullptr;
         ta.ovf_host = nullptr;
         ta.win_off = nullptr; ta.q_count = nullptr; ta.q_items = nullptr; ta.q_cap = 0; ta.pad4 = 0;
-        ta.res_items = n_res ? b->d_res_items.as<uint32_t>() : nullptr;
-        ta.n_res = (uint32_t)n_res; ta.res_lds_words = res_lds_words; ta.res_cell_cap = res_cell_cap; ta.res_ops_words = res_ops_words;
+        ResidentArgs xa;
+        xa.res_items = n_res ? b->d_res_items.as<uint32_t>() : nullptr;
+        xa.n_res = (uint32_t)n_res; xa.res_lds_words = res_lds_words; xa.res_cell_cap = res_cell_cap; xa.res_ops_words = res_ops_words;
         const bool zc = ctx->zero_copy != 0;
         if (zc) {
             // results land in pinned host memory while the kernel runs: [overflow word .. | PairOut x np | arena]
@@ -862,7 +863,7 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
             rs.launches++;
         }
         if (ctx->profiling) HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));     // end of the sweep = start of the traceback
-        if (n_res) HIP_TRY(swmi_launch_resident(&ta, ctx->stream));               // (timed with the traceback)
+        if (n_res) HIP_TRY(swmi_launch_resident(&ta, &xa, ctx->stream));          // (timed with the traceback)
         if (attempt == 0) b->timing.resident_pairs += (uint32_t)n_res;
         // (the exact-size re-run of pairs whose lists overflowed takes one workgroup per pair: its lists have no per-window cap)
         const bool split = rs.tb_split && !cells_exact && b->eff_mode == 1 && n_windows < 0xFFFFFFFFull;

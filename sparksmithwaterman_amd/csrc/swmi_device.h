@@ -162,8 +162,11 @@ struct TraceArgs {
     uint4          *q_items;     // {pair index of the launch, i, j, 0}
     uint32_t        q_cap;
     uint32_t        pad4;
-    // resident pairs (sw_resident_pairs_kernel): pairs whose whole direction field fits a wavefront's share of LDS
-    const uint32_t *res_items;   // indices into pairs[]
+};
+
+// extra arguments of sw_resident_pairs_kernel (kept out of TraceArgs: the traceback kernels are at their SGPR limit)
+struct ResidentArgs {
+    const uint32_t *res_items;   // indices into pairs[]: pairs whose whole direction field fits a wavefront's share of LDS
     uint32_t        n_res;
     uint32_t        res_lds_words;   // LDS dwords per wavefront (the largest resident pair of the launch)
     uint32_t        res_cell_cap;    // maximum cells a resident pair may list in LDS (more: SWMI_F_CELL_OVF, re-run by the ordinary path)

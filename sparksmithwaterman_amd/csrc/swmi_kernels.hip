@@ -1699,7 +1699,7 @@ __device__ __forceinline__ uint32_t wave_scan_add_u32(uint32_t v) {          // 
 }
 
 template <int R, bool STRICT>
-__device__ __forceinline__ void resident_pair(const TraceArgs &A, const PairDesc pd, const uint32_t lane, uint32_t *__restrict__ lds) {
+__device__ __forceinline__ void resident_pair(const TraceArgs &A, const ResidentArgs &X, const PairDesc pd, const uint32_t lane, uint32_t *__restrict__ lds) {
     const SeqDesc rd = A.refs[pd.ref_id];
     const SeqDesc qd = A.reads[pd.read_id];
     const uint32_t n = rd.len, m = qd.len;
@@ -1711,8 +1711,8 @@ __device__ __forceinline__ void resident_pair(const TraceArgs &A, const PairDesc
     uint32_t *field = lds;                                                  // [nblk][R][64]
     uint32_t *wmaxs = field + nblk * R * WAVE;
     uint2 *cells = reinterpret_cast<uint2 *>(wmaxs + ((n_ck + 1u) & ~1u));
-    uint32_t *opsb = reinterpret_cast<uint32_t *>(cells + A.res_cell_cap);
-    uint32_t *refc = opsb + WAVE * A.res_ops_words;
+    uint32_t *opsb = reinterpret_cast<uint32_t *>(cells + X.res_cell_cap);
+    uint32_t *refc = opsb + WAVE * X.res_ops_words;
     uint32_t *readc = refc + (n + 3u) / 4u + 1u;
     for (uint32_t w = lane; w < (n + 3u) / 4u; w += WAVE) refc[w] = refw[w];
     for (uint32_t w = lane; w < (m + 3u) / 4u; w += WAVE) readc[w] = readw[w];
@@ -1796,9 +1796,9 @@ __device__ __forceinline__ void resident_pair(const TraceArgs &A, const PairDesc
             const bool hot = (int)wmaxs[tb / SWMI_CK_BLOCKS] == pair_max;       // (wave-uniform: an LDS word)
             if (hot) {
                 if (steady) fill_block16<R, true, STRICT, false, false, SWMI_MODE_DETECT>(S, w, t0, lane, lane_eff, n, m, lane * R, A.gap, A.match, A.mismatch,
-                                                                                          0, false, false, nullptr, cells, A.res_cell_cap);
+                                                                                          0, false, false, nullptr, cells, X.res_cell_cap);
                 else        fill_block16<R, true, STRICT, false, true, SWMI_MODE_DETECT>(S, w, t0, lane, lane_eff, n, m, lane * R, A.gap, A.match, A.mismatch,
-                                                                                         0, false, false, nullptr, cells, A.res_cell_cap);
+                                                                                         0, false, false, nullptr, cells, X.res_cell_cap);
             } else {
                 if (steady) fill_block16<R, true, STRICT, false, false, SWMI_MODE_REPLAY>(S, w, t0, lane, lane_eff, n, m, lane * R, A.gap, A.match, A.mismatch,
                                                                                           0, false, false, nullptr, nullptr, 0u);
@@ -1815,23 +1815,23 @@ __device__ __forceinline__ void resident_pair(const TraceArgs &A, const PairDesc
         }
         ncell = S.cnt;
     }
-    po.score = pair_max; po.flags = ncell > A.res_cell_cap ? SWMI_F_CELL_OVF : 0u; po.n_cells = ncell;
+    po.score = pair_max; po.flags = ncell > X.res_cell_cap ? SWMI_F_CELL_OVF : 0u; po.n_cells = ncell;
     if (lane == 0) { A.out[pd.out_id] = po; if (A.out_host) A.out_host[pd.out_id] = po; }
-    if (ncell > A.res_cell_cap || ncell == 0u) return;            // (too many: the host re-runs the pair through the ordinary path)
+    if (ncell > X.res_cell_cap || ncell == 0u) return;            // (too many: the host re-runs the pair through the ordinary path)
     WAVE_SYNC();
 
     // ---- C: one lane per alignment ----------------------------------------------------------------------------------
     const uint8_t *ref_b = reinterpret_cast<const uint8_t *>(refc);
     const uint8_t *read_b = reinterpret_cast<const uint8_t *>(readc);
     const uint32_t umat = (uint32_t)A.match, umis = (uint32_t)A.mismatch, ugap = (uint32_t)A.gap;
-    const uint32_t max_ops = 16u * A.res_ops_words;
+    const uint32_t max_ops = 16u * X.res_ops_words;
     for (uint32_t base = 0; base < ncell; base += WAVE) {
         const bool mine = base + lane < ncell;
         const uint2 c0 = mine ? cells[base + lane] : make_uint2(0u, 0u);
         uint32_t i = c0.x, j = c0.y, score = (uint32_t)pair_max, nops = 0, cur = 0;
         int begin = 0;
         bool active = mine;
-        uint32_t *my_ops = opsb + lane * A.res_ops_words;
+        uint32_t *my_ops = opsb + lane * X.res_ops_words;
         while (BALLOT(active)) {
             if (active) {
                 const uint32_t rho = i - 1u, l = rho / R, k = rho - l * R;
@@ -1879,35 +1879,35 @@ __device__ __forceinline__ void resident_pair(const TraceArgs &A, const PairDesc
 }
 
 extern "C" __global__ void __launch_bounds__(WAVE * FILL_WAVES)
-sw_resident_pairs_kernel(const TraceArgs A) {
+sw_resident_pairs_kernel(const TraceArgs A, const ResidentArgs X) {
     extern __shared__ uint32_t rp_lds[];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t item = blockIdx.x * FILL_WAVES + wave;
-    if (item >= A.n_res) return;
+    if (item >= X.n_res) return;
     // (the arena header was reset by sw_sweep_winmax_kernel, one launch earlier; the traceback kernels append after this one)
-    const PairDesc pd = A.pairs[A.res_items[item]];
-    uint32_t *lds = rp_lds + wave * A.res_lds_words;
+    const PairDesc pd = A.pairs[X.res_items[item]];
+    uint32_t *lds = rp_lds + wave * X.res_lds_words;
     const uint32_t R = swmi_rows_per_lane(A.reads[pd.read_id].len);
     if (A.strict) {
-        if (R == 1)      resident_pair<1, true>(A, pd, lane, lds);
-        else if (R == 2) resident_pair<2, true>(A, pd, lane, lds);
-        else if (R == 3) resident_pair<3, true>(A, pd, lane, lds);
-        else             resident_pair<4, true>(A, pd, lane, lds);
+        if (R == 1)      resident_pair<1, true>(A, X, pd, lane, lds);
+        else if (R == 2) resident_pair<2, true>(A, X, pd, lane, lds);
+        else if (R == 3) resident_pair<3, true>(A, X, pd, lane, lds);
+        else             resident_pair<4, true>(A, X, pd, lane, lds);
     } else {
-        if (R == 1)      resident_pair<1, false>(A, pd, lane, lds);
-        else if (R == 2) resident_pair<2, false>(A, pd, lane, lds);
-        else if (R == 3) resident_pair<3, false>(A, pd, lane, lds);
-        else             resident_pair<4, false>(A, pd, lane, lds);
+        if (R == 1)      resident_pair<1, false>(A, X, pd, lane, lds);
+        else if (R == 2) resident_pair<2, false>(A, X, pd, lane, lds);
+        else if (R == 3) resident_pair<3, false>(A, X, pd, lane, lds);
+        else             resident_pair<4, false>(A, X, pd, lane, lds);
     }
 }
 
-extern "C" hipError_t swmi_launch_resident(const TraceArgs *a, hipStream_t st) {
-    if (a->n_res == 0) return hipSuccess;
+extern "C" hipError_t swmi_launch_resident(const TraceArgs *a, const ResidentArgs *x, hipStream_t st) {
+    if (x->n_res == 0) return hipSuccess;
     static const bool attr = [] { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(sw_resident_pairs_kernel),
                                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); return true; }();
     (void)attr;
-    hipLaunchKernelGGL(sw_resident_pairs_kernel, dim3((a->n_res + FILL_WAVES - 1) / FILL_WAVES), dim3(WAVE * FILL_WAVES),
-                       (size_t)FILL_WAVES * a->res_lds_words * sizeof(uint32_t), st, *a);
+    hipLaunchKernelGGL(sw_resident_pairs_kernel, dim3((x->n_res + FILL_WAVES - 1) / FILL_WAVES), dim3(WAVE * FILL_WAVES),
+                       (size_t)FILL_WAVES * x->res_lds_words * sizeof(uint32_t), st, *a, *x);
     return hipGetLastError();
 }
 

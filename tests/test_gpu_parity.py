@@ -71,7 +71,7 @@ def check_batch(ctx, refs, reads, scores=(5, -3, -4), types=("a", "i", "d", "-")
 
 def test_kats(ctx, kats):
     for k in kats:
-        b = ctx.upload([k["ref"]], [k["read"]]).run(sw.make_params(k["scores"], ("a", "i", "d", "-"), k["tie_mode"]))
+        b = ctx.upload([k["ref"]], [k["read"]]).run(sw.make_params(k["scores"], tuple(k.get("types", "aid-")), k["tie_mode"]))
         assert b.score(0) == k["score"], k["name"]
         assert [[x[0], x[1][0], x[1][1]] for x in b.alignments(0)] == k["alignments"], k["name"]
         if "map_ref_sorted" in k:

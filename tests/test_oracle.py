@@ -22,7 +22,7 @@ def _norm(alns):
 def test_kats_c_oracle(kats):
     for k in kats:
         if k.get("H"):
-            score, alns, H, T = orc.opt_alignments((k["ref"], k["read"]), k["scores"], b"aid-",
+            score, alns, H, T = orc.opt_alignments((k["ref"], k["read"]), k["scores"], k.get("types", "aid-").encode("latin-1"),
                                                    k["tie_mode"], matrices=True)
             assert H == k["H"], k["name"]
             if k.get("T"):
@@ -32,14 +32,14 @@ def test_kats_c_oracle(kats):
                         if H[i][j] > 0:
                             assert T[i][j] == ch, (k["name"], i, j)
         else:
-            score, alns = orc.opt_alignments((k["ref"], k["read"]), k["scores"], b"aid-", k["tie_mode"])
+            score, alns = orc.opt_alignments((k["ref"], k["read"]), k["scores"], k.get("types", "aid-").encode("latin-1"), k["tie_mode"])
         assert score == k["score"], k["name"]
         assert _norm(alns) == k["alignments"], k["name"]
 
 
 def test_kats_python_twin(kats):
     for k in kats:
-        score, alns = opy.opt_alignments((k["ref"], k["read"]), tuple(k["scores"]), ("a", "i", "d", "-"),
+        score, alns = opy.opt_alignments((k["ref"], k["read"]), tuple(k["scores"]), tuple(k.get("types", "aid-")),
                                          strict=bool(k["tie_mode"]))
         assert score == k["score"], k["name"]
         assert _norm(alns) == k["alignments"], k["name"]
