@@ -44,6 +44,7 @@
 #define SWMI_F_DEGENERATE   0x1u   // max score 0: all m*n cells tie (no alignment records emitted)
 #define SWMI_F_CELL_OVF     0x2u   // more tied max cells than cell_cap: host re-runs the pair
 #define SWMI_F_ARENA_OVF    0x4u   // a record of this pair did not fit the arena: host grows it, re-runs
+#define SWMI_F_DONE         0x8u   // the pair was handled whole by sw_resident_pairs_kernel: the traceback kernels leave it alone
 
 struct SeqDesc {
     uint32_t len;     // bases

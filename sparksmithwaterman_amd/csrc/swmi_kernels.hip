@@ -1458,10 +1458,9 @@ sw_traceback_winmax_kernel(const TraceArgs A) {
     // (rotating the walker role over the hardware waves, in case wave w always landed on SIMD w, changes nothing)
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const PairDesc pd = A.pairs[pair];
-    if (pd.pad & SWMI_PAD_RESIDENT) return;                  // done by sw_resident_pairs_kernel (same decision in every wave)
     PairOut po = A.out[pd.out_id];
     if (finish_pair(A, pd, po) && wave == 0 && lane == 0) A.out[pd.out_id] = po;
-    if (po.flags & SWMI_F_DEGENERATE) {                      // same decision in every wave: nobody waits at the barrier
+    if (po.flags & (SWMI_F_DEGENERATE | SWMI_F_DONE)) {      // (DONE: sw_resident_pairs_kernel did the whole pair) same decision in every wave: nobody waits at the barrier
         if (A.out_host && wave == 0 && lane == 0) A.out_host[pd.out_id] = po;
         return;
     }
@@ -1585,10 +1584,9 @@ sw_detect_windows_kernel(const TraceArgs A) {
     }
     const uint32_t pair = lo, wloc = item - A.win_off[pair];
     const PairDesc pd = A.pairs[pair];
-    if (pd.pad & SWMI_PAD_RESIDENT) return;                  // done by sw_resident_pairs_kernel
     PairOut po = A.out[pd.out_id];
     if (finish_pair(A, pd, po) && wloc == 0u && lane == 0) A.out[pd.out_id] = po;     // (window 0's wave completes the record)
-    if (po.flags & SWMI_F_DEGENERATE) return;
+    if (po.flags & (SWMI_F_DEGENERATE | SWMI_F_DONE)) return;                          // (DONE: sw_resident_pairs_kernel did the whole pair)
     const SeqDesc rd = A.refs[pd.ref_id];
     const SeqDesc qd = A.reads[pd.read_id];
     const uint32_t n = rd.len, m = qd.len;
@@ -1775,7 +1773,7 @@ __device__ __forceinline__ void resident_pair(const TraceArgs &A, const Resident
     }
     PairOut po;
     if (pair_max <= 0) {                                                   // every cell ties at 0: SmithWaterman.java:154,182-185
-        po.score = 0; po.flags = SWMI_F_DEGENERATE; po.n_cells = (uint64_t)m * n;
+        po.score = 0; po.flags = SWMI_F_DEGENERATE | SWMI_F_DONE; po.n_cells = (uint64_t)m * n;
         if (lane == 0) { A.out[pd.out_id] = po; if (A.out_host) A.out_host[pd.out_id] = po; }
         return;
     }
@@ -1815,7 +1813,7 @@ __device__ __forceinline__ void resident_pair(const TraceArgs &A, const Resident
         }
         ncell = S.cnt;
     }
-    po.score = pair_max; po.flags = ncell > X.res_cell_cap ? SWMI_F_CELL_OVF : 0u; po.n_cells = ncell;
+    po.score = pair_max; po.flags = SWMI_F_DONE | (ncell > X.res_cell_cap ? SWMI_F_CELL_OVF : 0u); po.n_cells = ncell;
     if (lane == 0) { A.out[pd.out_id] = po; if (A.out_host) A.out_host[pd.out_id] = po; }
     if (ncell > X.res_cell_cap || ncell == 0u) return;            // (too many: the host re-runs the pair through the ordinary path)
     WAVE_SYNC();
