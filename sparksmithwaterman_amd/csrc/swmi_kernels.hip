@@ -72,6 +72,11 @@ __device__ __forceinline__ uint32_t ld_l2(const uint32_t *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// A value every lane of the wave holds alike, moved to a scalar register: what hangs on it (loop bounds, branches,
+// base addresses) then runs on the scalar unit instead of as exec-masked vector code.
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint64_t uni64(uint64_t v) { return ((uint64_t)uni((uint32_t)(v >> 32)) << 32) | uni((uint32_t)v); }
+
 __device__ __forceinline__ uint32_t seq_code(const uint32_t *__restrict__ w, uint32_t pos) {
     return (w[pos >> 2] >> (8u * (pos & 3u))) & 0xFFu;
 }
@@ -589,6 +594,8 @@ __device__ __forceinline__ void sweep_step_ref(const int (&hin)[R], int (&hout)[
 
 template <int R, bool COLS>
 __device__ __forceinline__ void sweep_fast(const FillArgs &A, const PairDesc pd, const uint32_t lane, const ColItem ci) {
+    // (moving the pair's geometry to scalar registers with readfirstlane makes the block loop scalar, and the sweep 3 % slower:
+    // measured, tools/ab_headline.py -- the vector-side loop control overlaps the asm groups better than the scalar one)
     const SeqDesc rd = A.refs[pd.ref_id];
     const SeqDesc qd = A.reads[pd.read_id];
     const uint32_t n_full = rd.len, m = qd.len;

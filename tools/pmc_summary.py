@@ -66,6 +66,14 @@ def main():
     doc["fill_kernel"] = "sw_sweep_winmax_kernel (mode 1)"
     doc["fill_kernel_hbm_bytes_per_launch"] = hbm("sw_sweep_winmax_kernel")
     doc["traceback_kernel_hbm_bytes_per_launch"] = hbm("sw_traceback_winmax_kernel")
+    # instructions of the sweep per pair (steady launches: the minimum over the dispatches leaves out the first, cold ones)
+    mins = {(p_, k, c): mn for (p_, k, c, _n, _m, mn, _x) in summary}
+    v = mins.get(("sq", "sw_sweep_winmax_kernel", "SQ_INSTS_VALU"))
+    sa = mins.get(("sq", "sw_sweep_winmax_kernel", "SQ_INSTS_SALU"))
+    if v and sa:
+        doc["sweep_insts_per_pair_headline"] = {
+            "valu": int(round(v / 1000.0)), "salu": int(round(sa / 1000.0)),
+            "source": "SQ_INSTS_VALU / SQ_INSTS_SALU per launch / 1000 pairs (profiles/%s/pmc/pmc_summary_%s.csv), 150 x 2000 pairs only" % (rnd, tag)}
     json.dump(doc, open(path, "w"), indent=1)
     print(json.dumps(doc, indent=1))
 
