@@ -592,6 +592,43 @@ __device__ __forceinline__ void sweep_step_ref(const int (&hin)[R], int (&hout)[
     rbn = wave_shr1((int)(1u << (feed_code & 31u)), rb);
 }
 
+// 16 steps of a block in which some lane runs past the last column.  Such a lane goes on computing -- nobody reads its values:
+// the lane below it took what it needed one step earlier -- but its window maximum must not see them: SweepStepTailAsm updates
+// the maximum under a lane mask.  (-DSWMI_NO_ASM: the plain statement, which also leaves such a lane's state alone.)
+template <int R>
+__device__ __forceinline__ void sweep_tail_block(SweepState<R> &S, const uint4 w, const uint32_t wnext_x, const uint32_t t0,
+                                                 const uint32_t lane_eff, const uint32_t n, const int one, const uint32_t gm) {
+#ifndef SWMI_NO_ASM
+    const uint32_t c = t0 - lane_eff;              // column index (0-based) of this lane at step t0; lanes without rows: far outside
+    SweepStepTailAsm<R, 0>::run(S.h, S.g, S.hp, S.q, S.rbx, S.rby, w.x, w.y, one, gm, S.lmax, c + 0u, n);
+    SweepStepTailAsm<R, 1>::run(S.h, S.g, S.hp, S.q, S.rbx, S.rby, w.x, w.y, one, gm, S.lmax, c + 1u, n);
+    SweepStepTailAsm<R, 2>::run(S.h, S.g, S.hp, S.q, S.rbx, S.rby, w.x, w.y, one, gm, S.lmax, c + 2u, n);
+    SweepStepTailAsm<R, 3>::run(S.h, S.g, S.hp, S.q, S.rbx, S.rby, w.x, w.y, one, gm, S.lmax, c + 3u, n);
+    SweepStepTailAsm<R, 0>::run(S.h, S.g, S.hp, S.q, S.rbx, S.rby, w.y, w.z, one, gm, S.lmax, c + 4u, n);
+    SweepStepTailAsm<R, 1>::run(S.h, S.g, S.hp, S.q, S.rbx, S.rby, w.y, w.z, one, gm, S.lmax, c + 5u, n);
+    SweepStepTailAsm<R, 2>::run(S.h, S.g, S.hp, S.q, S.rbx, S.rby, w.y, w.z, one, gm, S.lmax, c + 6u, n);
+    SweepStepTailAsm<R, 3>::run(S.h, S.g, S.hp, S.q, S.rbx, S.rby, w.y, w.z, one, gm, S.lmax, c + 7u, n);
+    SweepStepTailAsm<R, 0>::run(S.h, S.g, S.hp, S.q, S.rbx, S.rby, w.z, w.w, one, gm, S.lmax, c + 8u, n);
+    SweepStepTailAsm<R, 1>::run(S.h, S.g, S.hp, S.q, S.rbx, S.rby, w.z, w.w, one, gm, S.lmax, c + 9u, n);
+    SweepStepTailAsm<R, 2>::run(S.h, S.g, S.hp, S.q, S.rbx, S.rby, w.z, w.w, one, gm, S.lmax, c + 10u, n);
+    SweepStepTailAsm<R, 3>::run(S.h, S.g, S.hp, S.q, S.rbx, S.rby, w.z, w.w, one, gm, S.lmax, c + 11u, n);
+    SweepStepTailAsm<R, 0>::run(S.h, S.g, S.hp, S.q, S.rbx, S.rby, w.w, wnext_x, one, gm, S.lmax, c + 12u, n);
+    SweepStepTailAsm<R, 1>::run(S.h, S.g, S.hp, S.q, S.rbx, S.rby, w.w, wnext_x, one, gm, S.lmax, c + 13u, n);
+    SweepStepTailAsm<R, 2>::run(S.h, S.g, S.hp, S.q, S.rbx, S.rby, w.w, wnext_x, one, gm, S.lmax, c + 14u, n);
+    SweepStepTailAsm<R, 3>::run(S.h, S.g, S.hp, S.q, S.rbx, S.rby, w.w, wnext_x, one, gm, S.lmax, c + 15u, n);
+#else
+#pragma unroll
+    for (uint32_t s = 0; s < 16; ++s) {
+        const uint32_t s1 = s + 1u;
+        const uint32_t wf = s1 < 4 ? w.x : s1 < 8 ? w.y : s1 < 12 ? w.z : s1 < 16 ? w.w : wnext_x;
+        const uint32_t code = (wf >> (8u * (s1 & 3u))) & 0xFFu;
+        const bool in_range = (t0 + s - lane_eff) < n;
+        if (s & 1u) sweep_step_ref<R>(S.g, S.h, S.hp, S.q, S.rby, S.rbx, code, gm, S.lmax, in_range);
+        else        sweep_step_ref<R>(S.h, S.g, S.hp, S.q, S.rbx, S.rby, code, gm, S.lmax, in_range);
+    }
+#endif
+}
+
 template <int R, bool COLS>
 __device__ __forceinline__ void sweep_fast(const FillArgs &A, const PairDesc pd, const uint32_t lane, const ColItem ci) {
     // (moving the pair's geometry to scalar registers with readfirstlane makes the block loop scalar, and the sweep 3 % slower:
@@ -671,15 +708,7 @@ __device__ __forceinline__ void sweep_fast(const FillArgs &A, const PairDesc pd,
         } else
 #endif
         {
-#pragma unroll
-            for (uint32_t s = 0; s < 16; ++s) {
-                const uint32_t s1 = s + 1u;
-                const uint32_t wf = s1 < 4 ? w.x : s1 < 8 ? w.y : s1 < 12 ? w.z : s1 < 16 ? w.w : wnext.x;
-                const uint32_t code = (wf >> (8u * (s1 & 3u))) & 0xFFu;
-                const bool in_range = (t0 + s - lane_eff) < n;
-                if (s & 1u) sweep_step_ref<R>(S.g, S.h, S.hp, S.q, S.rby, S.rbx, code, gm, S.lmax, in_range);
-                else        sweep_step_ref<R>(S.h, S.g, S.hp, S.q, S.rbx, S.rby, code, gm, S.lmax, in_range);
-            }
+            sweep_tail_block<R>(S, w, wnext.x, t0, lane_eff, n, one, gm);
         }
     }
     {
@@ -1763,15 +1792,7 @@ __device__ __forceinline__ void resident_pair(const TraceArgs &A, const Resident
             } else
 #endif
             {
-#pragma unroll
-                for (uint32_t s = 0; s < 16; ++s) {
-                    const uint32_t s1 = s + 1u;
-                    const uint32_t wf = s1 < 4 ? w.x : s1 < 8 ? w.y : s1 < 12 ? w.z : s1 < 16 ? w.w : wnext.x;
-                    const uint32_t code = (wf >> (8u * (s1 & 3u))) & 0xFFu;
-                    const bool in_range = (t0 + s - lane_eff) < n;
-                    if (s & 1u) sweep_step_ref<R>(S.g, S.h, S.hp, S.q, S.rby, S.rbx, code, gm, S.lmax, in_range);
-                    else        sweep_step_ref<R>(S.h, S.g, S.hp, S.q, S.rbx, S.rby, code, gm, S.lmax, in_range);
-                }
+                sweep_tail_block<R>(S, w, wnext.x, t0, lane_eff, n, one, gm);
             }
         }
         const int wm = wave_max_i32(lane < lact ? S.lmax : -1);

@@ -40,9 +40,11 @@ class Ins:
         self.states = 1
 
 
-def stream(R, odd, feed_byte):
+def stream(R, odd, feed_byte, tail=False):
     """instruction list of one step; register names are asm operand names.  Even steps read h / write g and consume
-    rbx / prepare rby; odd steps the other way round."""
+    rbx / prepare rby; odd steps the other way round.  tail: the step of a block in which some lanes have run past the last
+    column -- they compute values nobody reads, but their window maximum must not see them: it is updated under a lane
+    mask (v_cmp once per step, v_cndmask per update)."""
     H, G = ("g", "h") if odd else ("h", "g")
     RB, RBN = ("rby", "rbx") if odd else ("rbx", "rby")
     WF = "wf1" if feed_byte == 0 else "wf0"          # the last step of a group of four is fed from the next dword
@@ -51,6 +53,8 @@ def stream(R, odd, feed_byte):
     hp = lambda k: f"%[p{k}]"
     dpp = "wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0"
     ins = []
+    if tail:
+        ins.append(Ins("v_cmp_lt_u32_e32 vcc, %[c], %[n]", wr=["vcc"], rd=["c", "n"]))       # this lane's column is inside the reference
     ins.append(Ins(f"v_dot8_i32_i4 %[s0], %[q0], %[{RB}], 0", wr=["s0"], dot=["s0"], rd=["q0", RB]))
     for k in range(1, R):
         ins.append(Ins(f"v_dot8_i32_i4 %[a{k}], %[q{k}], %[{RB}], {hin(k-1)}", wr=[f"a{k}"], dot=[f"a{k}"], rd=[f"q{k}", RB, f"{H}{k-1}"]))
@@ -66,12 +70,21 @@ def stream(R, odd, feed_byte):
         ins.append(Ins(f"v_sub_u32_e64 {hp(k)}, {hout(k)}, %[gm] clamp", wr=[f"p{k}"], rd=[f"{G}{k}"]))
     # window maximum: even steps consume 2*floor(R/2) of their values, odd steps the leftover row of the even step + their own
     vals = [hout(k) for k in range(R)]
-    if not odd:
+    if tail:
+        # no deferral: a lane may be inside the reference at an even step and outside at the odd one, which would drop the row
+        # it left over -- every step takes all of its own values (the last one twice when R is odd)
+        if R % 2:
+            vals.append(vals[-1])
+    elif not odd:
         vals = vals[:2 * (R // 2)]
     elif R % 2:
         vals = [hin(R - 1)] + vals
     for j in range(0, len(vals), 2):
-        ins.append(Ins(f"v_max3_i32 %[lm], %[lm], {vals[j]}, {vals[j+1]}", wr=["lm"], rd=["lm"]))
+        if tail:
+            ins.append(Ins(f"v_max3_i32 %[x], %[lm], {vals[j]}, {vals[j+1]}", wr=["x"], rd=["lm"]))
+            ins.append(Ins("v_cndmask_b32_e32 %[lm], %[lm], %[x], vcc", wr=["lm"], rd=["lm", "x", "vcc"]))
+        else:
+            ins.append(Ins(f"v_max3_i32 %[lm], %[lm], {vals[j]}, {vals[j+1]}", wr=["lm"], rd=["lm"]))
     return ins
 
 
@@ -136,6 +149,35 @@ def emit(R):
     return "\n".join(L), n_valu, n_nop
 
 
+def emit_tail(R, ph):
+    """one masked step (phase ph of a block) as its own asm statement: the few blocks at the end of a sweep"""
+    odd = ph & 1
+    body = pad_hazards(stream(R, not odd, ph, True)[-4:], stream(R, odd, (ph + 1) & 3, True))
+    n_nop = sum(1 for i in body if i.text.startswith("s_nop"))
+    L = []
+    L.append(f"// R={R} phase {ph}: one masked step, {len(body) - n_nop} VALU, {n_nop} s_nop")
+    L.append(f"template <> struct SweepStepTailAsm<{R}, {ph}> {{")
+    L.append(f"    static __device__ __forceinline__ void run(int (&h)[{R}], int (&g)[{R}], int (&hp)[{R}], const int (&q)[{R}],")
+    L.append(f"                                               int &rbx, int &rby, const uint32_t wf0, const uint32_t wf1,")
+    L.append(f"                                               const int one, const uint32_t gm, int &lm, const uint32_t c, const uint32_t n) {{")
+    L.append("        int s0, a0, x" + "".join(f", a{k}" for k in range(1, R)) + ";")
+    L.append("        asm volatile(")
+    for i in body:
+        L.append(f'            "{i.text}\\n\\t"')
+    outs = [f'[h{k}] "+v"(h[{k}])' for k in range(R)] + [f'[g{k}] "+v"(g[{k}])' for k in range(R)]
+    outs += [f'[p{k}] "+v"(hp[{k}])' for k in range(R)]
+    outs += ['[rbx] "+v"(rbx)', '[rby] "+v"(rby)', '[lm] "+v"(lm)', '[s0] "=&v"(s0)', '[a0] "=&v"(a0)', '[x] "=&v"(x)']
+    outs += [f'[a{k}] "=&v"(a{k})' for k in range(1, R)]
+    ins_ = [f'[q{k}] "v"(q[{k}])' for k in range(R)]
+    ins_ += ['[wf0] "v"(wf0)', '[wf1] "v"(wf1)', '[one] "v"(one)', '[gm] "s"(gm)', '[c] "v"(c)', '[n] "v"(n)']
+    L.append("            : " + ", ".join(outs))
+    L.append("            : " + ", ".join(ins_))
+    L.append('            : "vcc");')
+    L.append("    }")
+    L.append("};")
+    return "\n".join(L)
+
+
 def main():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     path = os.path.join(root, "sparksmithwaterman_amd", "csrc", "swmi_step_gen.inc")
@@ -147,6 +189,13 @@ def main():
         parts.append(text)
         parts.append("")
         print(f"R={R}: {(nv + nn) / 4:.2f} instructions per step ({(nv + nn) / 4 / R:.2f} per cell), {nn} s_nop per 4 steps")
+    parts += ["// The same step for the blocks at the end of a sweep, where lanes run past the last column: one step per statement,",
+              "// the window maximum updated under a lane mask (see the script's docstring).",
+              "template <int R, int PH> struct SweepStepTailAsm;", ""]
+    for R in (1, 2, 3, 4):
+        for ph in range(4):
+            parts.append(emit_tail(R, ph))
+            parts.append("")
     with open(path, "w") as f:
         f.write("\n".join(parts))
     print("wrote", path)
