@@ -1061,8 +1061,10 @@ __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDes
         else if (idx < ncell) { mine.x = ld_l2(&cells[idx].x); mine.y = ld_l2(&cells[idx].y); }
         const uint64_t mykey = A.strict ? (((uint64_t)(mine.x + mine.y) << 32) | mine.y)
                                         : (((uint64_t)mine.x << 32) | mine.y);
-        uint32_t rank = one ? SWMI_RANK_BY_CELL : 0u;
-        if (ncell > 1) {
+        // (a pair with more tied cells than one wave of lanes: every lane comparing its cell with all others is O(cells^2)
+        //  global loads per walker -- 1600 cells on a 128 kbp periodic reference -- so the host orders those records by cell)
+        uint32_t rank = (one || ncell > WAVE) ? SWMI_RANK_BY_CELL : 0u;
+        if (ncell > 1 && ncell <= WAVE) {
             for (uint32_t o = 0; o < ncell; ++o) {
                 uint2 c; c.x = ld_l2(&cells[o].x); c.y = ld_l2(&cells[o].y);
                 const uint64_t kk = A.strict ? (((uint64_t)(c.x + c.y) << 32) | c.y) : (((uint64_t)c.x << 32) | c.y);

@@ -417,3 +417,28 @@ def test_resident_pairs_engineerdata_shapes(ctx):
             assert int(sc[k * 2 + q]) == es and b.alignments(k * 2 + q) == ea
     assert len(set(int(x) for x in sc[0:6000:2])) == 1 and len(set(int(x) for x in na[0:6000:2])) == 1
     b.free()
+
+
+def test_config4_full_size_pair(ctx):
+    """configs[4] at full size: one 10 kbp x 10 kbp pair (40 strips of 256 read rows, 10^8 cells) against the oracle --
+    score, every tied maximum, every alignment string (full size had only been checked run to run)."""
+    refs, reads = synth.config_long(n_pairs=1, length=10000, seed=4)
+    b = ctx.upload(refs, reads).run()
+    es, ea = orc.opt_alignments((refs[0], reads[0]))
+    assert b.score(0) == es
+    assert b.alignments(0) == ea
+    b.free()
+
+
+def test_many_tied_maxima_in_every_pair_of_a_large_launch(ctx):
+    """A launch large enough for one workgroup per pair (>= 64 pairs) whose pairs each carry more tied maxima than a wave
+    has lanes: the records come back unranked (SWMI_RANK_BY_CELL) and the host orders them by cell, in both tie orders."""
+    ref = REF * 70                                           # 5600 bp, one tied maximum per period
+    refs = [ref, ref[40:] + ref[:40], ref[::-1]] * 24        # 72 pairs per read
+    for tie in (0, 1):
+        b = ctx.upload(refs, [REF[10:50]]).run(sw.make_params((5, -3, -4), ("a", "i", "d", "-"), tie))
+        for k in (0, 1, 2, 71):
+            es, ea = orc.opt_alignments((refs[k], REF[10:50]), (5, -3, -4), b"aid-", tie)
+            assert b.score(k) == es and b.n_alignments(k)[0] == len(ea)
+            assert b.alignments(k) == ea
+        b.free()
