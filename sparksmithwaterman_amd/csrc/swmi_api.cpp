@@ -1761,7 +1761,9 @@ extern "C" int swmi_stream_open(swmi_ctx *ctx, const swmi_params *p, const uint8
         // the slot contexts run what the caller's context would run
         sl.ctx->cell_cap = ctx->cell_cap; sl.ctx->cell_cap_set = ctx->cell_cap_set; sl.ctx->max_workspace_bytes = ctx->max_workspace_bytes;
         sl.ctx->profiling = ctx->profiling; sl.ctx->mode = ctx->mode; sl.ctx->zero_copy = ctx->zero_copy;
-        sl.ctx->tb_split = ctx->tb_split; sl.ctx->col_chunks = ctx->col_chunks; sl.ctx->spin_us = 50;
+        sl.ctx->tb_split = ctx->tb_split; sl.ctx->col_chunks = ctx->col_chunks; sl.ctx->resident = ctx->resident;
+        sl.ctx->auto_ties_x100 = ctx->auto_ties_x100; sl.ctx->arena_words_per_pair = ctx->arena_words_per_pair;
+        sl.ctx->spin_us = 50;                    // (a chunk takes milliseconds: the slot threads mostly block)
         sl.shell = new swmi_batch;
     }
     // pinned buffers: one being parsed into per parser thread (up to 6), one per slot in flight, two queued

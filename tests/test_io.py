@@ -202,3 +202,43 @@ def test_stream_from_fasta_file_100k_references(tmp_path):
     assert st.stats().chunks == len(st.chunks()) >= 10
     st.close()
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_stream_errors_and_oversized_records(tmp_path):
+    """The stream's error paths (a missing file, a file without a leading metadata line: the reference dies with a
+    NullPointerException there, InOutOps.java:148) and a record longer than a chunk (its pinned buffer grows)."""
+    import numpy as np
+    from sparksmithwaterman_amd import synth
+    ctx = sw.Context(0)
+    reads = ["ACGTACGTTGCAACGTTGCA"]
+    st = ctx.stream(reads, slots=2, chunk_bytes=64 << 10)
+    with pytest.raises(sw.SwmiError):
+        st.push_file(tmp_path / "missing.fa")
+    st.close()
+    bad = tmp_path / "bad.fa"
+    bad.write_text("ACGT\n>gi|late\nACGT\n")
+    st = ctx.stream(reads, slots=2, chunk_bytes=64 << 10)
+    with pytest.raises(sw.SwmiError):
+        st.push_file(bad)
+    st.close()
+    # one 300 kbp record between short ones, chunks of 64 KiB
+    rng = synth.SplitMix64(77)
+    refs = [rng.bases(500), rng.bases(300000), rng.bases(700), rng.bases(70000)]
+    path = tmp_path / "big.fa"
+    _write_fasta(path, [r.decode() for r in refs])
+    st = ctx.stream(reads, slots=2, chunk_bytes=64 << 10)
+    st.push_file(path).finish()
+    b = ctx.upload(refs, reads).run()
+    assert list(st.totals()) == list(b.ref_totals())
+    assert st.n_refs() == 4 and len(st.chunks()) >= 2
+    assert [st.metadata(k) for k in range(4)] == [">gi|ref%d" % k for k in range(4)]
+    first, c = st.chunks()[-1]
+    assert c.alignments(c.n_refs * 1 - 1) == b.alignments(3)
+    st.close()
+    st = ctx.stream(reads, slots=1, chunk_bytes=64 << 10)
+    st.push(refs).finish()
+    assert list(st.totals()) == list(b.ref_totals())
+    st.close()
+    b.free()
+    ctx.close()
