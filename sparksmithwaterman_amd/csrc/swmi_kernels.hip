@@ -1033,6 +1033,7 @@ __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDes
     const int dec0 = A.match > A.mismatch ? A.match : A.mismatch;
     const uint32_t udec = dec0 > 0 ? (uint32_t)dec0 : 0u;    // the most one alignment move can lower the tracked score
     const uint32_t ugdec = A.gap > 0 ? (uint32_t)A.gap : 0u;  // ... and one gap move
+    (void)udec; (void)ugdec;                                  // (only the SWMI_WALK_DIAGONALS build of the walk uses them)
     const bool acgt = rd.acgt && qd.acgt && SWMI_SCORES_FIT(A);
 
     uint32_t *lds_ops = lds;                                   // [A.lds_words]      one op per BYTE, staged per alignment
@@ -1147,6 +1148,69 @@ __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDes
                 const unsigned long long tw0 = A.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
                 if (A.dbg) { tk_stage += tw0 - ts0; n_iters += 1ull << 32; }      // (stagings counted in the upper half)
 
+#ifdef SWMI_WALK_CHASE
+                // (Alternative walk, -DSWMI_WALK_CHASE: measured 0.084 ms against the 0.072 ms of the run-based walk below at the
+                //  headline config -- one wave issues an instruction of ANY kind every ~5.6 cycles, so 23 scalar instructions per
+                //  path step cost more than 145 instructions per 4.4 steps.  Kept as the simplest correct statement of the walk.)
+                // One LDS round trip brings the 8 x 8 NEIGHBOURHOOD up-left of the current cell into the
+                // wave: lane (a, b) = (lane >> 3, lane & 7) looks at cell (i - a, j - b) -- its direction bits, whether its two
+                // bases match, whether it is staged at all -- and packs that into one word.  The path is then chased through the
+                // neighbourhood by SCALAR code, one v_readlane per step (the lane index is the position in the neighbourhood):
+                // direction, H(pred) = H - delta (`while (score > 0)`, SmithWaterman.java:380-409), op, next cell -- about 15
+                // scalar instructions per path step and no memory access, 7-15 steps per round trip whatever mix of gaps and
+                // alignment moves the path is made of.
+                for (;;) {
+                    ++n_iters;
+                    const uint32_t na = lane >> 3, nb = lane & 7u;
+                    const int rho_x = rho - (int)na;
+                    const uint32_t rx = rho_x > 0 ? (uint32_t)rho_x : 0u;
+                    const uint32_t lx = rx / R, kx = rx - lx * R;
+                    const uint32_t jj = j - nb;                                    // column of this lane's cell
+                    const int tx = (int)jj - 1 + (int)lx;
+                    const bool valid = rho_x >= 0 && j > nb && tx >= tmin;         // same strip, inside the matrix, inside the staged span
+                    // all three LDS reads are issued together (one latency); lanes without a cell read element 0
+                    const uint32_t dw = lds_tile[valid ? (((uint32_t)tx >> 4) - wlo) * (R * WAVE) + kx * WAVE + lx : 0u];
+                    const uint32_t rc = ref_b[valid ? (jj - 1u) - 4u * cw0 : 0u];
+                    const uint32_t qc = read_b[valid ? i - 1u - na : 0u];
+                    const uint32_t d = (dw >> (2u * (15u - ((uint32_t)tx & 15u)))) & 3u;
+                    // everything a path step needs from this cell, worked out by its lane: the move (rows, columns), the op, the
+                    // score it takes off (:388-406), whether the move leaves the neighbourhood or reaches row / column 0
+                    const uint32_t b0 = d & 1u, b1 = (d >> 1) & 1u;                // alignment chosen; else insertion over deletion
+                    const uint32_t di = b0 | b1, dj = b0 | (b1 ^ 1u);
+                    const uint32_t op = (b0 << 1) | (b1 & (b0 ^ 1u));              // SWMI_DIR_A = 2, _I = 1, _D = 0
+                    const int delta = (int)(b0 ? (rc == qc ? umat : umis) : ugap);
+                    const uint32_t last = (na + di > 7u || nb + dj > 7u) ? 1u : 0u;
+                    const uint32_t edge = (i - na == di || j - nb == dj) ? 1u : 0u;
+                    const int ctrl = valid ? (int)(0x80000000u | (edge << 9) | (last << 8) | (op << 4) | (di << 3) | dj) : 0;
+                    // (the compiler does not know that i, j and score are the same in every lane: readfirstlane says so, and the
+                    //  chase below then compiles to scalar code with scalar branches instead of an exec-masked vector loop)
+                    const uint32_t si = uni(i), sj = uni(j);
+                    uint32_t sscore = uni(score);
+                    uint32_t idx = 0, sh = 0, opsacc = 0, lastc = 0, lastidx = 0;
+                    bool done = false;
+                    for (;;) {
+                        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane(ctrl, (int)idx);
+                        if ((int)c >= 0) break;                                     // not staged (or in the strip above): restage from here
+                        sscore -= (uint32_t)__builtin_amdgcn_readlane(delta, (int)idx);
+                        opsacc |= ((c >> 4) & 3u) << sh;
+                        sh += 2u;
+                        lastc = c; lastidx = idx;
+                        idx += c & 15u;
+                        if ((int)sscore <= 0) { done = true; break; }
+                        if (c & 0x300u) {                                           // the move left the neighbourhood (at most 15 ops: one word) ...
+                            if (c & 0x200u) { sscore = 0; done = true; }            // ... or reached row / column 0 (cannot happen with a positive score on consistent data)
+                            break;
+                        }
+                    }
+                    const uint32_t cnt = sh >> 1;
+                    const uint32_t ca = cnt ? (lastidx >> 3) + ((lastc >> 3) & 1u) : 0u, cb = cnt ? (lastidx & 7u) + (lastc & 7u) : 0u;
+                    score = sscore;
+                    if (cnt) begin = (int)(sj - (lastidx & 7u));                    // `beginning = j` of the last cell visited (:383)
+                    if (lane < cnt && n_ops + lane < 4u * A.lds_words) ops_b[n_ops + lane] = (uint8_t)((opsacc >> (2u * lane)) & 3u);
+                    n_ops += cnt; i = si - ca; j = sj - cb; rho -= (int)ca;
+                    if (done || cnt == 0u || rho < 0) break;                        // finished / the current cell needs another window or strip
+                }
+#else
                 // Three diagonals are inspected at once, 21 lanes each: group 0 runs up from the current cell, group 1
                 // from the cell above it (where an insertion leads), group 2 from the cell to its left (a deletion).
                 // One iteration then takes: [a gap move] + [the run of alignment moves that follows] + [the gap move
@@ -1252,6 +1316,7 @@ __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDes
                         if (rho < 0) break;
                     }
                 }
+#endif
                 if (A.dbg) tk_walk += __builtin_amdgcn_s_memtime() - tw0;
             }
             n_steps += n_ops;
