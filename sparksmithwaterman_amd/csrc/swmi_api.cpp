@@ -796,7 +796,8 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
         fa.hdr = (ArenaHdr *)res;
         fa.dbg = nullptr;
         fa.dbg_pad = 0;
-        if (getenv("SWMI_DEBUG_FILL")) {        // diagnostics: per-pair slow-path entries and wave cycles
+        static const bool dbg_fill = getenv("SWMI_DEBUG_FILL") != nullptr;      // (getenv walks the whole environment: once per process, not per run)
+        if (dbg_fill) {                          // diagnostics: per-pair slow-path entries and wave cycles
             if ((rc = b->d_dbg.reserve(np * 16))) return rc;
             fa.dbg = b->d_dbg.as<unsigned long long>();
             fa.dbg_thr0 = getenv("SWMI_DEBUG_THR0") ? (uint32_t)atoi(getenv("SWMI_DEBUG_THR0")) : 1u;
@@ -850,7 +851,7 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
             ta.arena = (uint32_t *)(hd + a_off);
         }
         ta.dbg = nullptr;
-        if (getenv("SWMI_DEBUG_FILL")) {
+        if (dbg_fill) {
             if ((rc = b->d_dbg2.reserve(np * 32))) return rc;
             HIP_TRY(hipMemsetAsync(b->d_dbg2.p, 0, np * 32, ctx->stream));
             ta.dbg = b->d_dbg2.as<unsigned long long>();
@@ -1131,13 +1132,16 @@ extern "C" int swmi_batch_run(swmi_ctx *ctx, swmi_batch *b, const swmi_params *p
     if (p->types[0] == p->types[1] || p->types[0] == p->types[2] || p->types[1] == p->types[2])
         return fail(SWMI_ERR_UNSUPPORTED, "alignTypes a/i/d must be pairwise distinct");
     std::lock_guard<std::mutex> g(ctx->mu);
-    const bool host_dbg = getenv("SWMI_DEBUG_HOST") != nullptr;
+    static const bool host_dbg = getenv("SWMI_DEBUG_HOST") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point c) {
         return std::chrono::duration<double, std::micro>(c - a).count();
     };
     const auto h0 = now();
-    HIP_TRY(hipSetDevice(ctx->device));
+    {   // (hipSetDevice costs microseconds even when nothing changes; a sub-millisecond batch notices)
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess || cur != ctx->device) HIP_TRY(hipSetDevice(ctx->device));
+    }
     b->params = *p;
     b->has_run = false;
 

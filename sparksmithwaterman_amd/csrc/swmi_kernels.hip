@@ -1036,6 +1036,7 @@ __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDes
     (void)udec; (void)ugdec;                                  // (only the SWMI_WALK_DIAGONALS build of the walk uses them)
     const bool acgt = rd.acgt && qd.acgt && SWMI_SCORES_FIT(A);
 
+    // (s_setprio for the walker over the helpers sharing its SIMD: measured, no effect)
     uint32_t *lds_ops = lds;                                   // [A.lds_words]      one op per BYTE, staged per alignment
     uint32_t *lds_read = lds_ops + A.lds_words;                // [A.lds_read_words] the read's codes
     uint32_t *lds_ref = lds_read + A.lds_read_words;           // [SWMI_TB_REFWIN_WORDS]
