@@ -81,6 +81,23 @@ __device__ __forceinline__ uint32_t seq_code(const uint32_t *__restrict__ w, uin
     return (w[pos >> 2] >> (8u * (pos & 3u))) & 0xFFu;
 }
 
+// The 8 x int4 score profiles of a lane's R rows (fast symbols): nibble c/4 of row k's profile is the score of the row's base
+// against reference symbol c.  The R base codes are loaded FIRST, unconditionally (images are padded), so that the loads are in
+// flight together: a load behind each `row < m` test serialised R memory latencies in front of every window re-sweep.
+template <int R>
+__device__ __forceinline__ void build_profiles(int (&q)[R], const uint32_t *__restrict__ readw, const uint32_t row0, const uint32_t m,
+                                               const int match, const int mismatch) {
+    uint32_t c[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) c[k] = seq_code(readw, row0 + k) & 28u;      // 0, 4, ..., 28
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        uint32_t p = (uint32_t)(mismatch & 0xF) * 0x11111111u;
+        if (row0 + k < m) p = (p & ~(0xFu << c[k])) | ((uint32_t)(match & 0xF) << c[k]);
+        q[k] = (int)p;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // the R cells of one lane in one step (previous column's H in hin, this column's H to hout)
 // ------------------------------------------------------------------------------------------------
@@ -196,19 +213,17 @@ struct FillState {
 template <int R, bool ACGT>
 __device__ __forceinline__ void setup_rows(FillState<R> &S, const uint32_t *__restrict__ readw, uint32_t row0, uint32_t m,
                                            int match, int mismatch) {
+    if (ACGT) {
+        build_profiles<R>(S.q, readw, row0, m, match, mismatch);      // 8 signed score nibbles indexed by the reference code
+    } else {
+        uint32_t c[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) c[k] = seq_code(readw, row0 + k);
+#pragma unroll
+        for (int k = 0; k < R; ++k) S.q[k] = row0 + k < m ? (int)c[k] : (int)SWMI_CODE_PAD;
+    }
 #pragma unroll
     for (int k = 0; k < R; ++k) {
-        const uint32_t row = row0 + k;
-        if (ACGT) {                                   // 8 signed score nibbles indexed by the reference code
-            uint32_t p = (uint32_t)(mismatch & 0xF) * 0x11111111u;
-            if (row < m) {
-                const uint32_t c = seq_code(readw, row);      // 0, 4, ..., 28
-                p = (p & ~(0xFu << c)) | ((uint32_t)(match & 0xF) << c);
-            }
-            S.q[k] = (int)p;
-        } else {
-            S.q[k] = row < m ? (int)seq_code(readw, row) : (int)SWMI_CODE_PAD;
-        }
         S.h[k] = 0;
         S.g[k] = 0;
         S.acc[k] = 0;
@@ -653,15 +668,9 @@ __device__ __forceinline__ void sweep_fast(const FillArgs &A, const PairDesc pd,
 
     const unsigned long long dbg_t0 = A.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
     SweepState<R> S;
+    build_profiles<R>(S.q, readw, lane * R, m, A.match, A.mismatch);
 #pragma unroll
     for (int k = 0; k < R; ++k) {
-        const uint32_t row = lane * R + k;
-        uint32_t p = (uint32_t)(A.mismatch & 0xF) * 0x11111111u;
-        if (row < m) {
-            const uint32_t c = seq_code(readw, row);      // 0, 4, ..., 28
-            p = (p & ~(0xFu << c)) | ((uint32_t)(A.match & 0xF) << c);
-        }
-        S.q[k] = (int)p;
         S.h[k] = 0; S.g[k] = 0; S.hp[k] = 0;
     }
     S.lmax = -1;
@@ -861,6 +870,52 @@ sw_sweep_winmax_cols_kernel(const FillArgs A) {
 #define SWMI_TB_WAVES 8u            // mode 1: most waves per workgroup (= per pair) of the traceback kernel; the launcher picks 4 or 8
 #endif
 
+// The same re-sweep for the usual pair (fast symbols, one strip, gap <= 0), from the shorter instruction stream of
+// tools/gen_step.py (DirStep4Asm: the 3-VALU cell + two compares feeding v_addc, neighbour exchange inside the arithmetic;
+// 25 instructions per step at R = 3 instead of ~30).  No lane is masked: a lane outside its column range computes bits
+// nobody reads, and because every step pushes exactly one bit pair the bits of the real steps sit where the walk expects them.
+template <int R, bool STRICT>
+__device__ __forceinline__ void replay_window_fast(const TraceArgs &A, const PairDesc pd, const uint32_t n, const uint32_t m,
+                                                   const uint32_t *__restrict__ refw, const uint32_t *__restrict__ readw,
+                                                   const uint32_t wlo, const uint32_t lane, uint32_t *__restrict__ lds_tile) {
+    const uint32_t gm = (uint32_t)(-(int64_t)A.gap);
+    const int one = 1;
+    int h[R], g[R], hp[R], q[R];
+    uint32_t acc[R];
+    const uint32_t *__restrict__ ck = A.dir + pd.dir_off + (uint64_t)(wlo / SWMI_CK_BLOCKS) * (R + 2) * WAVE + lane;
+    build_profiles<R>(q, readw, lane * R, m, A.match, A.mismatch);
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        h[k] = (int)ld_l2(ck + k * WAVE);
+        hp[k] = (uint32_t)h[k] > gm ? (int)((uint32_t)h[k] - gm) : 0;
+        g[k] = 0;
+        acc[k] = 0;
+    }
+    // the checkpoint holds, per lane, the N it received one step earlier (= NW of its row 0 now); the stream takes that value
+    // from the lane above, out of its ping-pong set: hand it back up (wave_shl:1)
+    const int nprev = (int)ld_l2(ck + R * WAVE);
+    g[R - 1] = __builtin_amdgcn_update_dpp(0, nprev, 0x130 /*wave_shl:1*/, 0xf, 0xf, true);
+    const int rb_ck = (int)ld_l2(ck + (R + 1) * WAVE);
+    const uint32_t lact = m >= WAVE * R ? WAVE : (m + R - 1) / R;
+    const uint32_t T = n + lact - 1, nblk = (T + 15u) / 16u;
+    const uint4 *__restrict__ refq = reinterpret_cast<const uint4 *>(refw);
+    uint4 wv[SWMI_CK_BLOCKS + 1];
+#pragma unroll
+    for (uint32_t b = 0; b <= SWMI_CK_BLOCKS; ++b) wv[b] = refq[wlo + b];          // images are padded past the last block
+    int rbx = wave_shr1((int)(1u << (wv[0].x & 31u)), rb_ck), rby = rb_ck;
+#pragma unroll
+    for (uint32_t b = 0; b < SWMI_CK_BLOCKS; ++b) {
+        if (wlo + b >= nblk) break;
+        const uint4 w = wv[b];
+        DirStep4Asm<R, STRICT>::run(h, g, hp, acc, q, rbx, rby, w.x, w.y, one, gm);
+        DirStep4Asm<R, STRICT>::run(h, g, hp, acc, q, rbx, rby, w.y, w.z, one, gm);
+        DirStep4Asm<R, STRICT>::run(h, g, hp, acc, q, rbx, rby, w.z, w.w, one, gm);
+        DirStep4Asm<R, STRICT>::run(h, g, hp, acc, q, rbx, rby, w.w, wv[b + 1].x, one, gm);
+#pragma unroll
+        for (int k = 0; k < R; ++k) lds_tile[(b * R + k) * WAVE + lane] = acc[k];
+    }
+}
+
 // re-sweep the window of SWMI_CK_BLOCKS blocks that starts at block `wlo` of strip `s` into lds_tile.
 // DETECT: also append the window's cells equal to `maxv` to the pair's cell list; returns the new list length.
 template <int R, bool ACGT, bool STRICT, bool MULTI, bool DETECT>
@@ -869,6 +924,14 @@ __device__ __forceinline__ uint32_t replay_window(const TraceArgs &A, const Pair
                                                   const StripGeom G, const uint32_t s, const uint32_t wlo,
                                                   const uint32_t lane, uint32_t *__restrict__ lds_tile,
                                                   const int maxv, const uint32_t cnt_in, uint2 *__restrict__ cells, const uint32_t ccap) {
+#ifndef SWMI_NO_ASM
+    if constexpr (ACGT && !MULTI && !DETECT) {
+        if (A.gap <= 0 && s == 0u) {
+            replay_window_fast<R, STRICT>(A, pd, n, m, refw, readw, wlo, lane, lds_tile);
+            return cnt_in;
+        }
+    }
+#endif
     constexpr int BM = DETECT ? SWMI_MODE_DETECT : SWMI_MODE_REPLAY;
     FillState<R> S;
     S.thr = DETECT ? maxv : 0x7FFFFFFF; S.cnt = cnt_in; S.ev_prev = 0; S.events = 0; S.dbg_skip = false; S.lmax = -1;
@@ -1826,17 +1889,9 @@ __device__ __forceinline__ void resident_pair(const TraceArgs &A, const Resident
         const uint32_t gm = (uint32_t)(-(int64_t)A.gap);
         const int one = 1;
         SweepState<R> S;
+        build_profiles<R>(S.q, readw, lane * R, m, A.match, A.mismatch);
 #pragma unroll
-        for (int k = 0; k < R; ++k) {
-            const uint32_t row = lane * R + k;
-            uint32_t p = (uint32_t)(A.mismatch & 0xF) * 0x11111111u;
-            if (row < m) {
-                const uint32_t c = seq_code(readw, row);
-                p = (p & ~(0xFu << c)) | ((uint32_t)(A.match & 0xF) << c);
-            }
-            S.q[k] = (int)p;
-            S.h[k] = 0; S.g[k] = 0; S.hp[k] = 0;
-        }
+        for (int k = 0; k < R; ++k) { S.h[k] = 0; S.g[k] = 0; S.hp[k] = 0; }
         S.lmax = -1;
         uint4 wnext = refq[0];
         S.rby = 0;

@@ -31,12 +31,14 @@ import sys
 
 DOT_WAIT = 3
 DPP_WAIT = 2
+SGPR_WAIT = 2     # gfx940/gfx950: a VALU writes an SGPR, a VALU reads it
 
 
 class Ins:
-    def __init__(self, text, wr=(), rd=(), dot=(), dpp_rd=(), dpp_wr=()):
+    def __init__(self, text, wr=(), rd=(), dot=(), dpp_rd=(), dpp_wr=(), sg_wr=(), sg_rd=()):
         self.text = text
         self.wr, self.rd, self.dot, self.dpp_rd, self.dpp_wr = tuple(wr), tuple(rd), tuple(dot), tuple(dpp_rd), tuple(dpp_wr)
+        self.sg_wr, self.sg_rd = tuple(sg_wr), tuple(sg_rd)      # SGPR pairs written by a VALU (v_cmp) / read by a VALU (v_addc)
         self.states = 1
 
 
@@ -107,6 +109,9 @@ def pad_hazards(prev_tail, body):
             for r in o.wr:
                 if r in i.dpp_rd or r in i.dpp_wr:
                     need = max(need, DPP_WAIT - states_since(pos))
+            for r in o.sg_wr:
+                if r in i.sg_rd:
+                    need = max(need, SGPR_WAIT - states_since(pos))
         if need > 0:
             nop = Ins(f"s_nop {need - 1}")
             nop.states = need
@@ -144,6 +149,96 @@ def emit(R):
     L.append("            : " + ", ".join(outs))
     L.append("            : " + ", ".join(ins_))
     L.append("            : );")
+    L.append("    }")
+    L.append("};")
+    return "\n".join(L), n_valu, n_nop
+
+
+def dir_stream(R, odd, feed_byte, strict):
+    """one step of the re-sweep WITH direction bits (the traceback's window replay): the 3-VALU cell plus two compares whose
+    lane masks feed v_addc as carry-in (acc = 2 * acc + bit), first `insertion beats deletion`, then `alignment beats both`:
+        serial ('>=' chain, SmithWaterman.java:223-249):  bI = hp(N) >= hp(W),  bA = (H == a)   [a >= max(hp, hp) <=> a is the max]
+        strict ('>' chain, DistributedSW.java:305-330):   bI = hp(N) >  hp(W),  bA = a > max(hp(N), hp(W))
+    On the clamped values hp = max(H + gap, 0) the compares only differ from the unclamped ones where both candidates are <= 0,
+    i.e. where the cell's direction is the alignment or its H is 0 and never read."""
+    H, G = ("g", "h") if odd else ("h", "g")
+    RB, RBN = ("rby", "rbx") if odd else ("rbx", "rby")
+    WF = "wf1" if feed_byte == 0 else "wf0"
+    hin = lambda k: f"%[{H}{k}]"
+    hout = lambda k: f"%[{G}{k}]"
+    hp = lambda k: f"%[p{k}]"
+    dpp = "wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0"
+    cmpI = "v_cmp_gt_u32_e64" if strict else "v_cmp_ge_u32_e64"
+    ins = []
+    ins.append(Ins(f"v_dot8_i32_i4 %[s0], %[q0], %[{RB}], 0", wr=["s0"], dot=["s0"], rd=["q0", RB]))
+    for k in range(1, R):
+        ins.append(Ins(f"v_dot8_i32_i4 %[a{k}], %[q{k}], %[{RB}], {hin(k-1)}", wr=[f"a{k}"], dot=[f"a{k}"], rd=[f"q{k}", RB, f"{H}{k-1}"]))
+    ins.append(Ins(f"v_lshlrev_b32_sdwa %[{RBN}], %[{WF}], %[one] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_{feed_byte} src1_sel:DWORD",
+                   wr=[RBN], rd=[WF, "one"]))
+    ins.append(Ins(f"v_mov_b32_dpp %[x], {hp(R-1)} {dpp}", wr=["x"], dpp_rd=[f"p{R-1}"]))                      # hp(N) of row 0
+    ins.append(Ins(f"v_add_u32_dpp %[a0], {hout(R-1)}, %[s0] {dpp}", wr=["a0"], rd=["s0"], dpp_rd=[f"{G}{R-1}"]))
+    ins.append(Ins(f"v_mov_b32_dpp %[{RBN}], %[{RB}] wave_shr:1 row_mask:0xf bank_mask:0xf", dpp_rd=[RB], dpp_wr=[RBN], wr=[RBN]))
+    # the second addc of a row waits two states for its compare: it is issued inside the NEXT row (and the last row's
+    # inside the next step, after its dot products -- emit_dir moves `trailing` there)
+    pending = None
+    for k in range(R):
+        up = "%[x]" if k == 0 else hp(k - 1)
+        upn = "x" if k == 0 else f"p{k-1}"
+        ak = "a0" if k == 0 else f"a{k}"
+        sI, sA = (("sI0", "sA0") if k % 2 == 0 else ("sI1", "sA1"))
+        ins.append(Ins(f"{cmpI} %[{sI}], {up}, {hp(k)}", rd=[upn, f"p{k}"], sg_wr=[sI]))
+        if strict:
+            ins.append(Ins(f"v_max_u32_e32 %[t], {up}, {hp(k)}", wr=["t"], rd=[upn, f"p{k}"]))
+        ins.append(Ins(f"v_max3_i32 {hout(k)}, %[{ak}], {up}, {hp(k)}", wr=[f"{G}{k}"], rd=[ak, upn, f"p{k}"]))
+        if pending:
+            ins.append(pending)
+        ins.append(Ins(f"v_sub_u32_e64 {hp(k)}, {hout(k)}, %[gm] clamp", wr=[f"p{k}"], rd=[f"{G}{k}"]))
+        if strict:
+            ins.append(Ins(f"v_cmp_gt_i32_e64 %[{sA}], %[{ak}], %[t]", rd=[ak, "t"], sg_wr=[sA]))
+        else:
+            ins.append(Ins(f"v_cmp_eq_u32_e64 %[{sA}], {hout(k)}, %[{ak}]", rd=[f"{G}{k}", ak], sg_wr=[sA]))
+        ins.append(Ins(f"v_addc_co_u32_e64 %[c{k}], vcc, %[c{k}], %[c{k}], %[{sI}]", wr=[f"c{k}"], rd=[f"c{k}"], sg_rd=[sI]))
+        pending = Ins(f"v_addc_co_u32_e64 %[c{k}], vcc, %[c{k}], %[c{k}], %[{sA}]", wr=[f"c{k}"], rd=[f"c{k}"], sg_rd=[sA])
+    return ins, pending
+
+
+def emit_dir(R, strict):
+    group = []
+    trailing = None
+    for ph in range(4):
+        body, last = dir_stream(R, ph & 1, (ph + 1) & 3, strict)
+        if trailing:
+            body.insert(min(R, 2), trailing)           # after the step's first dot products
+        group += body
+        trailing = last
+    group.append(trailing)
+    prev, plast = dir_stream(R, 1, 0, strict)
+    body = pad_hazards((prev + [plast])[-4:], group)
+    n_nop = sum(1 for i in body if i.text.startswith("s_nop"))
+    n_valu = len(body) - n_nop
+    L = []
+    L.append(f"// R={R} {'STRICT' if strict else 'SERIAL'}: four steps with direction bits, {n_valu} VALU, {n_nop} s_nop  ({n_valu / 4:.2f} per step, {n_valu / 4 / R:.2f} per cell)")
+    L.append(f"template <> struct DirStep4Asm<{R}, {'true' if strict else 'false'}> {{")
+    L.append(f"    static __device__ __forceinline__ void run(int (&h)[{R}], int (&g)[{R}], int (&hp)[{R}], uint32_t (&acc)[{R}], const int (&q)[{R}],")
+    L.append(f"                                               int &rbx, int &rby, const uint32_t wf0, const uint32_t wf1,")
+    L.append(f"                                               const int one, const uint32_t gm) {{")
+    L.append("        int s0, a0, x" + (", t" if strict else "") + "".join(f", a{k}" for k in range(1, R)) + ";")
+    L.append("        unsigned long long sI0, sA0, sI1, sA1;")
+    L.append("        asm volatile(")
+    for i in body:
+        L.append(f'            "{i.text}\\n\\t"')
+    outs = [f'[h{k}] "+v"(h[{k}])' for k in range(R)] + [f'[g{k}] "+v"(g[{k}])' for k in range(R)]
+    outs += [f'[p{k}] "+v"(hp[{k}])' for k in range(R)] + [f'[c{k}] "+v"(acc[{k}])' for k in range(R)]
+    outs += ['[rbx] "+v"(rbx)', '[rby] "+v"(rby)', '[s0] "=&v"(s0)', '[a0] "=&v"(a0)', '[x] "=&v"(x)']
+    if strict:
+        outs += ['[t] "=&v"(t)']
+    outs += [f'[a{k}] "=&v"(a{k})' for k in range(1, R)]
+    outs += ['[sI0] "=&s"(sI0)', '[sA0] "=&s"(sA0)', '[sI1] "=&s"(sI1)', '[sA1] "=&s"(sA1)']
+    ins_ = [f'[q{k}] "v"(q[{k}])' for k in range(R)]
+    ins_ += ['[wf0] "v"(wf0)', '[wf1] "v"(wf1)', '[one] "v"(one)', '[gm] "s"(gm)']
+    L.append("            : " + ", ".join(outs))
+    L.append("            : " + ", ".join(ins_))
+    L.append('            : "vcc");')
     L.append("    }")
     L.append("};")
     return "\n".join(L), n_valu, n_nop
@@ -196,6 +291,14 @@ def main():
         for ph in range(4):
             parts.append(emit_tail(R, ph))
             parts.append("")
+    parts += ["// The re-sweep with direction bits (window replay of the traceback), four steps per statement.",
+              "template <int R, bool STRICT> struct DirStep4Asm;", ""]
+    for R in (1, 2, 3, 4):
+        for strict in (False, True):
+            text, nv, nn = emit_dir(R, strict)
+            parts.append(text)
+            parts.append("")
+            print(f"R={R} {'strict' if strict else 'serial'} with direction bits: {(nv + nn) / 4:.2f} instructions per step, {nn} s_nop per 4 steps")
     with open(path, "w") as f:
         f.write("\n".join(parts))
     print("wrote", path)
