@@ -76,6 +76,9 @@ def main():
             "source": "SQ_INSTS_VALU / SQ_INSTS_SALU per launch / 1000 pairs (profiles/%s/pmc/pmc_summary_%s.csv), 150 x 2000 pairs only" % (rnd, tag)}
     json.dump(doc, open(path, "w"), indent=1)
     print(json.dumps(doc, indent=1))
+    # gpurun MERGES what a call wrote into the local gpurun_out/: a second collection would be summarised together with the
+    # first one's files.  The raw files are scratch once condensed.
+    shutil.rmtree(SRC, ignore_errors=True)
 
 
 if __name__ == "__main__":
