@@ -100,6 +100,10 @@ void        swmi_default_params(swmi_params *p);
  *                (80 bp reads x 400 bp references, the reference's EngineerData shapes) are handled start to finish by one
  *                wavefront -- two sweeps inside LDS, all alignments walked at once, one per lane; 0 never; 1 whenever the
  *                field fits 40 KB.
+ * tfused: -1 (default) in launches of >= 256 pairs, the usual pair -- fast symbols on both sides, scores within int4, gap < 0,
+ *                a read of at most 256 bases, a reference of at most 2560 -- is swept in the TRANSPOSED layout (reference
+ *                columns on the lanes, the read streaming through) and traced back by the same wavefront in the same
+ *                launch (sw_tfused_kernel); 0 never; 1 in launches of any size.
  * Further knobs: spin_us (how long a run polls its stream before it blocks, default 2000); col_chunks (0 automatic,
  * 1 never, N > 1 force up to N column chunks per pair: a launch of few pairs with long references is swept by several
  * wavefronts per pair); debug_strip_spins / debug_reverse_strips (tests of the strip pipeline's give-up path). */
@@ -133,7 +137,7 @@ typedef struct swmi_timing {
     uint32_t strip_fallbacks;   /* launches repeated with the one-wavefront sweep after the strip pipeline gave up */
     uint32_t col_chunks;        /* column-chunk wavefronts the sweep of the run was split into (0: one per pair)    */
     uint32_t resident_pairs;    /* pairs handled whole by one wavefront with the direction field in LDS             */
-    uint32_t pad;
+    uint32_t tfused_pairs;      /* pairs swept in the transposed layout and traced back by the same wavefront        */
 } swmi_timing;
 int  swmi_batch_timing(const swmi_batch *b, swmi_timing *t);
 /* The kernel pipeline (0, 1 or 2, see swmi_set_option "mode") the last run of the batch used. */

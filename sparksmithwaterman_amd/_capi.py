@@ -31,7 +31,7 @@ class Timing(C.Structure):
                 ("total_ms", C.c_float), ("fill_launches", C.c_uint32), ("rerun_pairs", C.c_uint32),
                 ("cells", C.c_uint64), ("dir_bytes", C.c_uint64),
                 ("strip_fallbacks", C.c_uint32), ("col_chunks", C.c_uint32),
-                ("resident_pairs", C.c_uint32), ("pad", C.c_uint32)]
+                ("resident_pairs", C.c_uint32), ("tfused_pairs", C.c_uint32)]
 
 
 class StreamStats(C.Structure):

@@ -12,6 +12,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <unistd.h>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -33,6 +34,7 @@ extern "C" hipError_t swmi_launch_fill(const FillArgs *a, hipStream_t st);
 extern "C" hipError_t swmi_launch_traceback(const TraceArgs *a, hipStream_t st);
 extern "C" hipError_t swmi_launch_traceback_split(const TraceArgs *a, uint32_t n_windows, hipStream_t st);
 extern "C" hipError_t swmi_launch_resident(const TraceArgs *a, const ResidentArgs *x, hipStream_t st);
+extern "C" hipError_t swmi_launch_tfused(const TraceArgs *a, const TFusedArgs *x, hipStream_t st);
 extern "C" hipError_t swmi_launch_encode(const uint8_t *raw, const uint64_t *raw_off, SeqDesc *desc, uint32_t *seqw,
                                          const uint8_t *lut, uint32_t n_seq, hipStream_t st);
 
@@ -113,6 +115,8 @@ struct swmi_ctx {
     uint64_t arena_copy_wpp = 48;           // arena words per pair fetched with the first D2H (tracks the last run)
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     PinnedBuf h_err;                        // one host-mapped word the kernels raise on an internal failure (strip pipeline timeout)
+    DevBuf d_hdr_ring;                      // arena headers of launches that run sw_tfused_kernel / sw_resident_pairs_kernel ONLY: a fresh zeroed
+    uint32_t hdr_next = 0;                  // slot per launch, so that no kernel has to run first just to reset the bump pointer
     DevBuf d_lut;                           // 256-byte canonical-code table of the encode kernel
     int64_t spin_us = 2000;                 // how long a run polls its stream for completion before it blocks (a batch is sub-millisecond)
     uint32_t dbg_strip_spins = 0;           // test knob: spin budget of the strip pipeline (0 = default)
@@ -121,6 +125,7 @@ struct swmi_ctx {
     uint32_t auto_ties_x100 = 300;          // automatic mode: mode 0 when a sampled pair has this many tied maxima (x 1/100) on average
     uint32_t col_chunks = 0;                // test knob: force this many column chunks per pair (0 = automatic)
     int tb_split = -1;                      // mode-1 traceback grain: -1 automatic, 0 one workgroup per pair, 1 one wavefront per window / alignment
+    int tfused = -1;                        // transposed sweep + traceback by one wavefront per pair (swmi_tfused.hip): -1 automatic, 0 never, 1 whenever a pair qualifies
     int resident = -1;                      // small pairs handled by one wavefront with the direction field in LDS: -1 automatic, 0 never, 1 whenever it fits
     bool cell_cap_set = false;              // cell_cap given by the caller (otherwise small launches get longer lists)
     // swmi_batch_run_async: one run in flight on the context's own host thread
@@ -177,6 +182,7 @@ struct swmi_batch {
     DevBuf d_strip_items, d_progress;       // mode 1: strip-per-wavefront sweep of long reads
     DevBuf d_col_items;                     // mode 1: column chunks of single-strip pairs
     DevBuf d_win_off, d_queue;              // split traceback: per-pair window offsets, walk-item queue
+    DevBuf d_tf_items;                      // pairs of the launch taken by sw_tfused_kernel
     DevBuf d_res_items;                     // resident pairs of the launch
     bool views_built = false;               // some MapRef view of the last run was built (they are reset by the next run)
     bool tb_split_used = false;             // the last run used the split traceback
@@ -208,6 +214,9 @@ struct swmi_batch {
         size_t n_res = 0;
         uint32_t res_lds_words = 0, res_ops_words = 0;
         int resident_opt = -1;
+        int tfused_opt = -1;
+        size_t n_tf = 0;
+        uint32_t tf_max_m = 0, tf_max_n = 0, tf_max_path = 0;
         bool exact = false;
         uint32_t col_chunks_opt = 0;
         bool reverse_strips = false;
@@ -259,6 +268,7 @@ static void ctx_release(swmi_ctx *c) {
     if (c->stream) (void)hipStreamDestroy(c->stream);
     c->h_err.release();
     c->d_lut.release();
+    c->d_hdr_ring.release();
     delete c;
 }
 
@@ -337,6 +347,9 @@ extern "C" int swmi_set_option(swmi_ctx *ctx, const char *name, int64_t value) {
         ctx->dbg_strip_spins = (uint32_t)value;
     } else if (!strcmp(name, "debug_reverse_strips")) {
         ctx->dbg_reverse_strips = value != 0;
+    } else if (!strcmp(name, "tfused")) {
+        if (value < -1 || value > 1) return fail(SWMI_ERR_INVALID, "tfused must be -1 (automatic), 0 or 1");
+        ctx->tfused = (int)value;
     } else if (!strcmp(name, "resident")) {
         if (value < -1 || value > 1) return fail(SWMI_ERR_INVALID, "resident must be -1 (automatic), 0 or 1");
         ctx->resident = (int)value;
@@ -560,17 +573,21 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
     std::vector<uint32_t> res_items;         // pairs handled whole by sw_resident_pairs_kernel
     size_t n_res = 0;
     uint32_t res_lds_words = 0, res_ops_words = 0;
+    std::vector<uint32_t> tf_items;          // pairs handled whole by sw_tfused_kernel (transposed sweep + traceback)
+    size_t n_tf = 0;
+    uint32_t tf_max_m = 0, tf_max_n = 0, tf_max_path = 0;
     const uint32_t res_cell_cap = 128;
     swmi_batch::Prep &pr = b->prep;
     const bool prepared = pr.valid && pr.lo == lo && pr.hi == hi && pr.work == (const void *)work.data() && pr.mode == b->eff_mode &&
                           memcmp(&pr.params, &b->params, sizeof(swmi_params)) == 0 && b->pairs_dev_ptr == b->d_pairs.p &&
                           b->pairs_on_device.size() == np * sizeof(PairDesc) && pr.col_chunks_opt == ctx->col_chunks &&
                           pr.reverse_strips == (ctx->dbg_reverse_strips != 0) && pr.resident_opt == ctx->resident &&
-                          pr.exact == (cells_exact != nullptr);
+                          pr.tfused_opt == ctx->tfused && pr.exact == (cells_exact != nullptr);
     if (prepared) {
         dir_words = pr.dir_words; seam_words = pr.seam_words; max_path = pr.max_path; max_read = pr.max_read;
         n_strip_items = pr.n_strip_items; n_col_items = pr.n_col_items; n_windows = pr.n_windows;
         n_res = pr.n_res; res_lds_words = pr.res_lds_words; res_ops_words = pr.res_ops_words;
+        n_tf = pr.n_tf; tf_max_m = pr.tf_max_m; tf_max_n = pr.tf_max_n; tf_max_path = pr.tf_max_path;
     } else {
     // Column chunks (swmi_device.h: ColItem): a launch of few pairs leaves most of the 1024 SIMDs idle while every pair is
     // one dependent chain of n + 63 steps.  A positive-score path spans at most m + match*m/|gap| columns (A <= m
@@ -601,7 +618,12 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
             res_maybe = m_ <= 64u * SWMI_RMAX && (ctx->resident == 1 || (uint64_t)n_ <= 8ull * m_) &&
                         res_need_words(m_, n_, opw) * 4 <= (ctx->resident == 1 ? 40u : 20u) * 1024u;
         }
-    if ((cols_possible || res_maybe) && !b->acgt_known) {
+    // Transposed, fused pairs (swmi_tfused.hip): reference columns on the lanes, the read streaming through, sweep AND
+    // traceback by one wavefront in one launch -- for the usual pair (fast symbols, int4 scores, gap < 0, read <= 256,
+    // reference <= 2560).  A launch of few pairs is latency-bound and keeps the several-wavefronts-per-pair paths.
+    const bool tf_possible = b->eff_mode == 1 && !cells_exact && ctx->tfused != 0 && (ctx->tfused == 1 || np >= 256) &&
+                             P.match > 0 && P.match <= 7 && P.mismatch >= -8 && P.mismatch <= P.match && P.gap < 0 && P.gap >= -64;
+    if ((cols_possible || res_maybe || tf_possible) && !b->acgt_known) {
         // the fast-symbol flags are derived on the device by the encode kernel
         if (b->n_refs) HIP_TRY(hipMemcpy(b->ref_desc.data(), b->d_refs.p, b->n_refs * sizeof(SeqDesc), hipMemcpyDeviceToHost));
         if (b->n_reads) HIP_TRY(hipMemcpy(b->read_desc.data(), b->d_reads.p, b->n_reads * sizeof(SeqDesc), hipMemcpyDeviceToHost));
@@ -631,7 +653,14 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
         const bool res_fit = res_maybe && m_ <= 64u * SWMI_RMAX && b->read_desc[d.read_id].acgt && b->ref_desc[d.ref_id].acgt &&
                              (ctx->resident == 1 || (uint64_t)n_ <= 8ull * m_) &&
                              res_need_words(m_, n_, res_opw) * 4 <= (ctx->resident == 1 ? 40u : 20u) * 1024u;
-        if (res_fit) {
+        const bool tf_fit = !res_fit && tf_possible && m_ <= SWMI_TF_MAX_M && n_ <= 64u * SWMI_TF_BMAX &&
+                            b->read_desc[d.read_id].acgt && b->ref_desc[d.ref_id].acgt && w.dir_words >= swmi_tf_ck_words(m_);
+        if (tf_fit) {
+            d.pad = SWMI_PAD_RESIDENT;                  // (every other kernel skips the pair)
+            tf_items.push_back((uint32_t)k);
+            tf_max_m = std::max(tf_max_m, m_); tf_max_n = std::max(tf_max_n, n_);
+            tf_max_path = std::max<uint32_t>(tf_max_path, (uint32_t)path_bound(n_, m_, P));
+        } else if (res_fit) {
             d.pad = SWMI_PAD_RESIDENT;
             res_items.push_back((uint32_t)k);
             uint32_t opw;
@@ -676,6 +705,7 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
     n_strip_items = strip_items.size();
     n_col_items = col_items.size();
     n_res = res_items.size();
+    n_tf = tf_items.size();
     // the kernel lays every wavefront's LDS out with the launch-wide ops_words: size the share for that
     res_lds_words = 0;
     for (uint32_t k : res_items) {
@@ -708,6 +738,11 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
         HIP_TRY(hipMemcpyAsync(b->d_res_items.p, res_items.data(), res_items.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));      // res_items is a local
     }
+    if (!prepared && !tf_items.empty()) {
+        if ((rc = b->d_tf_items.reserve(tf_items.size() * sizeof(uint32_t)))) return rc;
+        HIP_TRY(hipMemcpyAsync(b->d_tf_items.p, tf_items.data(), tf_items.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));      // tf_items is a local
+    }
     if (!prepared && !col_items.empty()) {
         if ((rc = b->d_col_items.reserve(col_items.size() * sizeof(ColItem)))) return rc;
         HIP_TRY(hipMemcpyAsync(b->d_col_items.p, col_items.data(), col_items.size() * sizeof(ColItem), hipMemcpyHostToDevice, ctx->stream));
@@ -730,6 +765,7 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
         pr.n_strip_items = n_strip_items; pr.n_col_items = n_col_items; pr.n_windows = n_windows;
         pr.n_res = n_res; pr.res_lds_words = res_lds_words; pr.res_ops_words = res_ops_words;
         pr.resident_opt = ctx->resident; pr.exact = cells_exact != nullptr;
+        pr.tfused_opt = ctx->tfused; pr.n_tf = n_tf; pr.tf_max_m = tf_max_m; pr.tf_max_n = tf_max_n; pr.tf_max_path = tf_max_path;
         pr.col_chunks_opt = ctx->col_chunks; pr.reverse_strips = ctx->dbg_reverse_strips != 0;
     }
     if (seam_words) HIP_TRY(hipMemsetAsync(b->d_seam.p, 0, seam_words * 4, ctx->stream));
@@ -840,6 +876,18 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
         ResidentArgs xa;
         xa.res_items = n_res ? b->d_res_items.as<uint32_t>() : nullptr;
         xa.n_res = (uint32_t)n_res; xa.res_lds_words = res_lds_words; xa.res_cell_cap = res_cell_cap; xa.res_ops_words = res_ops_words;
+        TFusedArgs xt{};
+        xt.items = n_tf ? b->d_tf_items.as<uint32_t>() : nullptr;
+        xt.n_items = (uint32_t)n_tf;
+        xt.cell_cap = 16;
+        xt.tile_words = ((tf_max_m + 63u + 15u) / 16u) * 64u * SWMI_TF_BR;
+        xt.ops_words = (tf_max_path + 15u) / 16u + 1u;
+        xt.ref_words = (tf_max_n + 3u) / 4u + 1u;
+        xt.read_words = (tf_max_m + 3u) / 4u + 1u;
+        xt.stage_words = (tf_max_path + 3u) / 4u + 1u;
+        static const bool tf_marks = getenv("SWMI_DEBUG_MARKS") != nullptr;
+        xt.debug_marks = tf_marks ? 1u : 0u;
+        xt.lds_words = (xt.tile_words + 2u * xt.cell_cap + xt.cell_cap * xt.ops_words + xt.stage_words + xt.ref_words + xt.read_words + 3u) & ~3u;
         const bool zc = ctx->zero_copy != 0;
         if (zc) {
             // results land in pinned host memory while the kernel runs: [overflow word .. | PairOut x np | arena]
@@ -857,15 +905,30 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
             ta.dbg = b->d_dbg2.as<unsigned long long>();
         }
 
-        if (attempt == 0) {       // the workspace survives an arena-overflow retry
+        // Every pair handled whole by sw_tfused_kernel / sw_resident_pairs_kernel: the sweep kernel would run only to zero the
+        // arena header.  Such a launch takes its header from a ring of zeroed slots instead (results in pinned memory only: a
+        // D2H copy fetches the header with the block it sits in).
+        const bool whole_only = zc && n_tf + n_res == np;
+        if (whole_only) {
+            const uint32_t slots = 1024;
+            if (!ctx->d_hdr_ring.p || ctx->hdr_next >= slots) {
+                if ((rc = ctx->d_hdr_ring.reserve((size_t)slots * 64))) return rc;
+                HIP_TRY(hipMemsetAsync(ctx->d_hdr_ring.p, 0, (size_t)slots * 64, ctx->stream));
+                ctx->hdr_next = 0;
+            }
+            ta.hdr = (ArenaHdr *)(ctx->d_hdr_ring.as<uint8_t>() + (size_t)ctx->hdr_next++ * 64);
+        }
+        if (ctx->profiling) HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
+        if (attempt == 0 && !whole_only) {       // the workspace survives an arena-overflow retry
             if (fa.n_strip_items) HIP_TRY(hipMemsetAsync(fa.progress, 0, (size_t)fa.n_strip_items * sizeof(uint32_t), ctx->stream));
-            if (ctx->profiling) HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
             HIP_TRY(swmi_launch_fill(&fa, ctx->stream));
             rs.launches++;
         }
+        if (n_tf) HIP_TRY(swmi_launch_tfused(&ta, &xt, ctx->stream));             // (sweep AND traceback of its pairs: timed with the sweep)
         if (ctx->profiling) HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));     // end of the sweep = start of the traceback
         if (n_res) HIP_TRY(swmi_launch_resident(&ta, &xa, ctx->stream));          // (timed with the traceback)
         if (attempt == 0) b->timing.resident_pairs += (uint32_t)n_res;
+        if (attempt == 0) b->timing.tfused_pairs += (uint32_t)n_tf;
         // (the exact-size re-run of pairs whose lists overflowed takes one workgroup per pair: its lists have no per-window cap)
         const bool split = rs.tb_split && !cells_exact && b->eff_mode == 1 && n_windows < 0xFFFFFFFFull;
         if (split) {
@@ -877,7 +940,7 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
             ta.q_cap = (uint32_t)q_cap;
             HIP_TRY(hipMemsetAsync(ta.q_count, 0, 4, ctx->stream));
             HIP_TRY(swmi_launch_traceback_split(&ta, (uint32_t)n_windows, ctx->stream));
-        } else if (n_res < np) {
+        } else if (n_res + n_tf < np) {
             HIP_TRY(swmi_launch_traceback(&ta, ctx->stream));
         }
         if (ctx->profiling) HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
@@ -890,6 +953,19 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
             if ((rc = b->h_result.reserve(a_off + arena_cap * 4))) return rc;
             HIP_TRY(hipMemcpyAsync(b->h_result.p, res, copy_bytes, hipMemcpyDeviceToHost, ctx->stream));
             if (ctx->profiling) HIP_TRY(hipEventRecord(ctx->ev[4], ctx->stream));
+        }
+        static const char *watchdog = getenv("SWMI_DEBUG_WATCHDOG");      // diagnostics: give up on a launch that does not end, show the kernel's marks
+        if (watchdog) {
+            const auto w0 = std::chrono::steady_clock::now();
+            while (hipStreamQuery(ctx->stream) == hipErrorNotReady)
+                if (std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count() > atof(watchdog)) {
+                    const volatile uint32_t *hm = (const volatile uint32_t *)b->h_result.p;
+                    fprintf(stderr, "[swmi watchdog] launch still running after %s s; marks:", watchdog);
+                    for (int k = 0; k < 12; k++) fprintf(stderr, " %08x", hm ? hm[k] : 0u);
+                    fprintf(stderr, "\n");
+                    fflush(stderr);
+                    _exit(3);
+                }
         }
         const auto c1 = std::chrono::steady_clock::now();
         {   // a batch is sub-millisecond: poll the stream for spin_us (this context only, no process-wide spin flag), then block
@@ -916,13 +992,22 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
         rs.wait_us += std::chrono::duration<double, std::micro>(c2 - c1).count();
         if (ctx->profiling) {
             float ms = 0;
-            if (attempt == 0) { HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1])); rs.fill_ms += ms; }
+            if (attempt == 0 || whole_only) { HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1])); rs.fill_ms += ms; }
             HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[3])); rs.tb_ms += ms;
             if (!zc) { HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4])); rs.d2h_ms += ms; }
         }
         if (ta.dbg) {
             std::vector<unsigned long long> d(np * 4);
             HIP_TRY(hipMemcpy(d.data(), ta.dbg, np * 32, hipMemcpyDeviceToHost));
+            if (n_tf) {          // sw_tfused_kernel's own fields: {ticks, sweep | prologue << 32, replay << 16 | steps, replays | walk << 32}
+                double t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0; unsigned long long mx = 0;
+                for (size_t k = 0; k < np; k++) {
+                    t0 += d[4*k]; t1 += d[4*k+1] & 0xFFFFFFFFull; t2 += d[4*k+1] >> 32; t3 += d[4*k+2] >> 16; t4 += d[4*k+3] >> 32; t5 += d[4*k+3] & 0xFFFFFFFFull;
+                    mx = std::max(mx, d[4*k]);
+                }
+                fprintf(stderr, "[swmi tfused dbg] ticks per pair: total mean=%.0f max=%llu = prologue %.0f + sweep %.0f + block re-sweeps %.0f (%.2f per pair) + walks %.0f + rest %.0f\n",
+                        t0 / np, mx, t2 / np, t1 / np, t3 / np, t5 / np, t4 / np, (t0 - t1 - t2 - t3 - t4) / np);
+            }
             double a0 = 0, a1 = 0, a2 = 0, a3 = 0; unsigned long long mx = 0;
             double a4 = 0;
             for (size_t k = 0; k < np; k++) { a0 += d[4*k]; a1 += d[4*k+1] & 0xFFFFFFFFull; a2 += d[4*k+2] & 0xFFFF; a4 += d[4*k+2] >> 16; a3 += d[4*k+3] & 0xFFFFFFFFull; mx = std::max(mx, d[4*k]); }
@@ -984,7 +1069,7 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
         if (zc) {
             overflow = *(const volatile uint32_t *)h != 0u;
             if (overflow) {        // rare: how much was needed is in the device-side header
-                HIP_TRY(hipMemcpy(&hdr_copy, res, sizeof hdr_copy, hipMemcpyDeviceToHost));
+                HIP_TRY(hipMemcpy(&hdr_copy, ta.hdr, sizeof hdr_copy, hipMemcpyDeviceToHost));
                 hdr = &hdr_copy;
             }
         } else {
@@ -1765,7 +1850,7 @@ extern "C" int swmi_stream_open(swmi_ctx *ctx, const swmi_params *p, const uint8
         // the slot contexts run what the caller's context would run
         sl.ctx->cell_cap = ctx->cell_cap; sl.ctx->cell_cap_set = ctx->cell_cap_set; sl.ctx->max_workspace_bytes = ctx->max_workspace_bytes;
         sl.ctx->profiling = ctx->profiling; sl.ctx->mode = ctx->mode; sl.ctx->zero_copy = ctx->zero_copy;
-        sl.ctx->tb_split = ctx->tb_split; sl.ctx->col_chunks = ctx->col_chunks; sl.ctx->resident = ctx->resident;
+        sl.ctx->tb_split = ctx->tb_split; sl.ctx->col_chunks = ctx->col_chunks; sl.ctx->resident = ctx->resident; sl.ctx->tfused = ctx->tfused;
         sl.ctx->auto_ties_x100 = ctx->auto_ties_x100; sl.ctx->arena_words_per_pair = ctx->arena_words_per_pair;
         sl.ctx->spin_us = 50;                    // (a chunk takes milliseconds: the slot threads mostly block)
         sl.shell = new swmi_batch;

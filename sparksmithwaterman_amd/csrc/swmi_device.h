@@ -174,6 +174,32 @@ struct ResidentArgs {
     uint32_t        res_ops_words;   // dwords of packed ops a lane can stage (the longest possible path of the launch)
 };
 
+// extra arguments of sw_tfused_kernel (swmi_tfused.hip): pairs swept in the transposed layout and traced back by the same wavefront
+struct TFusedArgs {
+    const uint32_t *items;       // indices into pairs[]
+    uint32_t        n_items;
+    uint32_t        lds_words;   // LDS dwords per wavefront: tile | cells | ops | reference codes | read codes
+    uint32_t        tile_words;  // direction tile of one block: ceil((m_max + 63) / 16) * 64 * SWMI_TF_BR
+    uint32_t        cell_cap;    // alignments one pair may have here (one lane each; more: SWMI_F_CELL_OVF, re-run by the ordinary path)
+    uint32_t        ops_words;   // dwords of packed ops a lane can stage (the longest possible path of the launch)
+    uint32_t        ref_words;   // LDS dwords for the longest reference's codes
+    uint32_t        read_words;  // ... and the longest read's
+    uint32_t        stage_words; // LDS dwords for the ops of ONE alignment staged one per byte (the longest possible path)
+    uint32_t        debug_marks; // diagnostics: workgroup 0 leaves progress marks in the host-mapped result header
+    uint32_t        pad;
+};
+#define SWMI_TF_BMAX   40u          // columns per lane of the transposed sweep: references up to 64 * 40 = 2560 bases
+#define SWMI_TF_BR     5u           // columns per lane of a re-swept block (320 columns: a 150 bp read's path fits with room)
+#define SWMI_TF_MAX_M  256u         // reads up to 256 bases (LDS tile of a block: (m + 63) / 16 KB)
+// columns per lane for a reference of n bases (even: the kernel is instantiated for 2, 4, ..., SWMI_TF_BMAX)
+SWMI_HD static inline uint32_t swmi_tf_cols_per_lane(uint32_t n) {
+    uint32_t b = (n + 63u) / 64u;
+    b = (b + 1u) & ~1u;
+    return b < 2u ? 2u : b;
+}
+// dwords of column checkpoints of a pair swept by sw_tfused_kernel: one 64-lane row per step, m + L - 1 <= m + 63 steps
+SWMI_HD static inline uint64_t swmi_tf_ck_words(uint32_t m) { return ((uint64_t)m + 64u) * 64u; }
+
 #define SWMI_RANK_BY_CELL 0xFFFFFFFFu   // AlnRec.rank of the split traceback: the host orders a pair's records by (end_i, end_j)
 #define SWMI_DETECT_LCAP  64u           // cells one window may hold before the pair is handed to the exact-size re-run
 
@@ -190,7 +216,10 @@ SWMI_HD static inline uint64_t swmi_dir_words(uint32_t m, uint32_t n, uint32_t m
     uint64_t wblocks = ((uint64_t)n + 63u + 15u) / 16u;   // T = n + 63 steps at most
     if (mode == 0) return strips * wblocks * R * 64u;
     uint64_t n_ck = (wblocks + SWMI_CK_BLOCKS - 1u) / SWMI_CK_BLOCKS;
-    return strips * (n_ck * (R + 2u) * 64u + (mode == 1 ? ((n_ck + 63u) & ~(uint64_t)63u) : 0u));
+    uint64_t words = strips * (n_ck * (R + 2u) * 64u + (mode == 1 ? ((n_ck + 63u) & ~(uint64_t)63u) : 0u));
+    // (a pair the transposed kernel may take keeps its column checkpoints in the same region)
+    if (mode == 1 && m <= 256u && n <= 64u * 40u && ((uint64_t)m + 64u) * 64u > words) words = ((uint64_t)m + 64u) * 64u;
+    return words;
 }
 // int32 seam rows of a pair whose read spans several strips: one row of n+1 per strip
 SWMI_HD static inline uint64_t swmi_seam_words(uint32_t m, uint32_t n) {

@@ -1,0 +1,569 @@
+// swmi_tfused.hip -- gfx950 kernel: ONE WAVEFRONT DOES ONE PAIR FROM START TO FINISH, in the TRANSPOSED layout.
+//
+// Same results as the sweep + traceback kernels of swmi_kernels.hip (ScoreMatrix.call src/sw/SmithWaterman.java:129-190,
+// GetCellScore.call :217-252 / DistributedSW.java:305-330, GetAlignment.call :354-436) for the usual pair: both sequences of
+// fast symbols, int4 scores, gap < 0, a read of at most 256 bases, a reference of at most 64 * SWMI_TF_BMAX bases.
+//
+// Why transposed.  The sweep of swmi_kernels.hip puts the READ's rows on the lanes (R = 3 rows per lane at 150 bp) and
+// streams the reference through: n + 63 steps of 3 R cell instructions + ~8 of per-step overhead (neighbour exchange, symbol
+// feed, window maximum, checkpoints).  At 150 x 2000 that is 2050 x 17 = 34.8 k instructions per pair, half of them overhead,
+// and the chip is issue- (in fact power-) bound: tools/ubench_occ.hip, 0.41 G wave-instructions/s per SIMD with one wave,
+// 0.55 with eight.  Here the lanes own the REFERENCE's columns, B = ceil(n / 64) consecutive columns each (B = 32 at 2 kbp),
+// and the read's rows stream through: m + 63 steps of 3.5 B + ~8 instructions = 214 x 120 = 25.7 k.  The per-step overhead is
+// paid 214 times instead of 2050 times; what the pipeline fill costs more (64 of 214 steps instead of 50 of 2050) is less.
+//
+//   A  sweep: lane l, step t, row i = t - l, columns B*l .. B*l+B-1.  Per cell v_dot8_i32_i4 (one-hot read symbol . the
+//      column's 8 x int4 score profile + the diagonal), v_max3_i32, v_sub_u32 clamp (hp = max(H + gap, 0)), and half a
+//      v_max3 for the lane's running maximum.  N comes from the lane's own registers, W from the cell before in the same
+//      step, NW/W of a lane's first column from lane l-1 by DPP.  The read symbol moves down the lanes by one DPP shift per
+//      step.  Every step each lane stores the H of its LAST column: 256 coalesced bytes -- column checkpoints
+//      ck[t][l] = H(t - l, B*(l+1) - 1), (m + 63) x 256 B per pair (55 KB at 150 bp, against 83 KB of lane-state checkpoints
+//      before).  Lanes that have not started compute zeros from zeros, lanes past the read's end and padding columns see a
+//      zero one-hot / zero profile and cannot exceed the true maximum: no masking anywhere.
+//   B  the lanes whose maximum equals the pair's name the candidate stripes.  A BLOCK of 64 * TF_BR (320) columns whose left edge is a
+//      checkpointed column is re-swept with TF_BR columns per lane, the left column fed from the checkpoints, rows streaming from
+//      a zero top row: scores are kept x 4 with the move in the two low bits (alignment 2 > insertion 1 > deletion 0, or the
+//      reverse for the strict mode), so that ONE v_max3 yields score and direction with the reference's tie order; the two
+//      bits are shifted into a direction word per column (v_alignbit) and every 16 steps a lane stores its words to LDS.
+//      Cells equal to the maximum are listed on the way.
+//   C  all alignments of the pair are walked at once, one LANE each, through the block in LDS (score tracked like
+//      SmithWaterman.java:380-409); lanes that leave the block on the left wait, the block that holds the rightmost of them is
+//      re-swept, and so on.  Records are appended to the arena exactly like sw_resident_pairs_kernel does.
+// More tied cells than lanes reserved: SWMI_F_CELL_OVF, no records, the host re-runs the pair through the ordinary path.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include "swmi_device.h"
+
+#define WAVE 64
+#define TF_WAVES 4
+#define TF_BR SWMI_TF_BR                 // columns per lane of a re-swept block
+#define TF_BW (64u * TF_BR)              // ... and its width
+#define BALLOT(pred) __builtin_amdgcn_ballot_w64(pred)
+#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+
+namespace {
+
+__device__ __forceinline__ int tf_shr1(int old, int src) { return __builtin_amdgcn_update_dpp(old, src, 0x138 /*wave_shr:1*/, 0xf, 0xf, false); }
+__device__ __forceinline__ int tf_shr1_zero(int src) { return __builtin_amdgcn_update_dpp(0, src, 0x138, 0xf, 0xf, true); }
+__device__ __forceinline__ int tf_ror1(int src) { return __builtin_amdgcn_update_dpp(src, src, 0x13C /*wave_ror:1*/, 0xf, 0xf, false); }
+__device__ __forceinline__ int tf_max3(int a, int b, int c) { const int t = a > b ? a : b; return t > c ? t : c; }
+__device__ __forceinline__ int tf_subsat(int a, uint32_t b) { return (int)__builtin_elementwise_sub_sat((uint32_t)a, b); }
+
+__device__ __forceinline__ int tf_wave_max(int v) {
+#define TF_DPP_MAX(ctrl, rmask) { int o_ = __builtin_amdgcn_update_dpp(v, v, ctrl, rmask, 0xf, false); v = v > o_ ? v : o_; }
+    TF_DPP_MAX(0x111, 0xf) TF_DPP_MAX(0x112, 0xf) TF_DPP_MAX(0x114, 0xf) TF_DPP_MAX(0x118, 0xf) TF_DPP_MAX(0x142, 0xa) TF_DPP_MAX(0x143, 0xc)
+#undef TF_DPP_MAX
+    return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ uint32_t tf_scan_add(uint32_t v) {          // inclusive prefix sum over the 64 lanes
+#define TF_DPP_ADD(ctrl, rmask) { const uint32_t o_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rmask, 0xf, true); v += o_; }
+    TF_DPP_ADD(0x111, 0xf) TF_DPP_ADD(0x112, 0xf) TF_DPP_ADD(0x114, 0xf) TF_DPP_ADD(0x118, 0xf) TF_DPP_ADD(0x142, 0xa) TF_DPP_ADD(0x143, 0xc)
+#undef TF_DPP_ADD
+    return v;
+}
+__device__ __forceinline__ uint32_t tf_lanes_below(uint64_t mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+__device__ __forceinline__ uint32_t tf_ld_l2(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t tf_uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+// 8 x int4 score profile of one reference column: nibble c/4 = score of the column's base against read symbol c
+__device__ __forceinline__ int tf_profile(uint32_t code, bool inside, int match, int mismatch) {
+    uint32_t p = (uint32_t)(mismatch & 0xF) * 0x11111111u;
+    const uint32_t sh = code & 28u;
+    p = (p & ~(0xFu << sh)) | ((uint32_t)(match & 0xF) << sh);
+    return inside ? (int)p : 0;
+}
+
+struct TfPair {
+    uint32_t n, m, B, L;             // reference / read length, columns per lane of the sweep, lanes that hold columns
+    const uint8_t *ref_b, *read_b;   // LDS copies of the byte images
+    uint32_t *ck;                    // column checkpoints [step][lane]
+    int match, mismatch;
+    uint32_t g;                      // -gap > 0
+};
+
+// ---- A: the score sweep --------------------------------------------------------------------------------------------
+template <int B>
+__device__ __forceinline__ int tf_sweep(const TfPair &P, const uint32_t lane, int &lane_max) {
+    int H[B], hp[B], q[B];
+#pragma unroll
+    for (int k = 0; k < B; ++k) {
+        const uint32_t c = (uint32_t)B * lane + (uint32_t)k;
+        q[k] = tf_profile(P.ref_b[c < P.n ? c : 0u], c < P.n, P.match, P.mismatch);
+        H[k] = 0; hp[k] = 0;
+    }
+    int nwL = 0, M = 0, oh = 0;
+    const uint32_t T = P.m + P.L - 1u;
+    uint32_t *__restrict__ ckp = P.ck + lane;
+    for (uint32_t t0 = 0; t0 < T; t0 += 64u) {
+        const uint32_t idx = t0 + 63u - lane;
+        int Q = idx < P.m ? (int)(1u << (P.read_b[idx] & 28u)) : 0;       // lane 63 holds the symbol of step t0, lane 62 of t0 + 1, ...
+        const uint32_t tend = T - t0 < 64u ? T - t0 : 64u;
+
+        for (uint32_t r = 0; r < tend; ++r) {
+            Q = tf_ror1(Q);
+            oh = tf_shr1(Q, oh);                                       // the symbol moves one lane down; lane 0 takes the next one
+            const int nw_next = tf_shr1_zero(H[B - 1]);                // lane l-1 finished this row one step ago: W's H now, NW next step
+            const int hpL = tf_shr1_zero(hp[B - 1]);
+#pragma unroll
+            for (int k = B - 1; k >= 1; --k) H[k] = __builtin_amdgcn_sdot8(oh, q[k], H[k - 1], true);    // NW + s, in place
+            H[0] = __builtin_amdgcn_sdot8(oh, q[0], nwL, true);
+            nwL = nw_next;
+            int w = hpL;
+#pragma unroll
+            for (int k = 0; k < B; ++k) {
+                const int x = tf_max3(H[k], hp[k], w);                  // SmithWaterman.java:223-249 with hp = max(H + gap, 0)
+                H[k] = x;
+                w = tf_subsat(x, P.g);
+                hp[k] = w;
+            }
+#pragma unroll
+            for (int k = 0; k + 1 < B; k += 2) M = tf_max3(M, H[k], H[k + 1]);
+            if (B & 1) M = M > H[B - 1] ? M : H[B - 1];
+            ckp[(size_t)(t0 + r) * WAVE] = (uint32_t)H[B - 1];
+        }
+    }
+    lane_max = M;
+    return tf_wave_max(M);
+}
+
+// ---- B: one block of TF_BW columns with directions ---------------------------------------------------------------------
+// Block = columns c_lo .. c_lo + TF_BW - 1, c_lo = B*k.  Lane la owns columns c_lo + TF_BR la + kk.  tile[((t/16)*TF_BR + kk)*64 + la]
+// holds the 16 steps t = 16 q .. 16 q + 15 of column kk of lane la, step t at bits 2*(t%16); step t of lane la is row t - la.
+// Cells equal to `pmax` inside columns [acc_lo, acc_hi) are counted, and those numbered base .. base + cell_cap - 1 (in the order
+// they are met) listed in cells[] (1-based i, j); returns the count.
+struct TfReplayState {
+    int Hs[TF_BR], hpN[TF_BR];
+    uint32_t dw[TF_BR];
+    int nwL, wlast, oh, Q, Bq, gmax;
+};
+
+// 16 steps.  LIST = false: the lane's maximum over the group is kept (2 instructions per step); LIST = true: every step tests
+// its four cells and appends the hits -- run only for a group whose maximum reached the pair's, from the saved state.
+template <bool STRICT, bool LIST>
+__device__ __forceinline__ uint32_t tf_replay_group(TfReplayState &S, const int (&q)[TF_BR], const uint32_t subW, const uint32_t subN,
+                                                    const uint32_t tg, const uint32_t lane, const TfPair &P, const uint32_t c_lo,
+                                                    const int target, const uint32_t acc_lo, const uint32_t acc_hi,
+                                                    uint2 *__restrict__ cells, const uint32_t cell_cap, const uint32_t base, uint32_t cnt) {
+    constexpr int TAGH = STRICT ? 0 : 2;
+#pragma unroll
+    for (uint32_t rr = 0; rr < 16u; ++rr) {
+        S.Q = tf_ror1(S.Q);
+        S.oh = tf_shr1(S.Q, S.oh);
+        S.Bq = tf_ror1(S.Bq);
+        const int nw_next = tf_shr1(S.Bq, S.Hs[TF_BR - 1]);                  // lane 0: the boundary column
+        const int hpL = tf_shr1(tf_subsat(S.Bq, subW), S.wlast);
+        int a[TF_BR];
+#pragma unroll
+        for (int kk = TF_BR - 1; kk >= 1; --kk) a[kk] = __builtin_amdgcn_sdot8(S.oh, q[kk], S.Hs[kk - 1], true);
+        a[0] = __builtin_amdgcn_sdot8(S.oh, q[0], S.nwL, true);
+        S.nwL = nw_next;
+        int w = hpL;
+#pragma unroll
+        for (int kk = 0; kk < TF_BR; ++kk) {
+            const int x = tf_max3(a[kk], S.hpN[kk], w);              // the low two bits name the winner, ties by the reference's order
+            S.dw[kk] = __builtin_amdgcn_alignbit((uint32_t)x, S.dw[kk], 2u);
+            S.Hs[kk] = (x & ~3) | TAGH;
+            w = tf_subsat(S.Hs[kk], subW);
+            S.hpN[kk] = tf_subsat(S.Hs[kk], subN);
+        }
+        S.wlast = w;
+        if (!LIST) {
+#pragma unroll
+            for (int kk = 0; kk + 1 < TF_BR; kk += 2) S.gmax = tf_max3(S.gmax, S.Hs[kk], S.Hs[kk + 1]);
+            if (TF_BR & 1) S.gmax = S.gmax > S.Hs[TF_BR - 1] ? S.gmax : S.Hs[TF_BR - 1];
+        } else {
+            const int row = (int)(tg + rr) - (int)lane;
+#pragma unroll
+            for (int kk = 0; kk < TF_BR; ++kk) {
+                const uint32_t c = c_lo + TF_BR * lane + (uint32_t)kk;
+                const bool ok = S.Hs[kk] == target && row >= 0 && row < (int)P.m && c < P.n && c >= acc_lo && c < acc_hi;
+                const uint64_t mk = BALLOT(ok);
+                if (mk) {
+                    const uint32_t pos = cnt + tf_lanes_below(mk);
+                    if (ok && pos >= base && pos - base < cell_cap) cells[pos - base] = make_uint2((uint32_t)row + 1u, c + 1u);
+                    cnt += (uint32_t)__builtin_popcountll(mk);
+                }
+            }
+        }
+    }
+    return cnt;
+}
+
+template <bool STRICT>
+__device__ __forceinline__ uint32_t tf_replay(const TfPair &P, const uint32_t lane, const uint32_t k_stripe, uint32_t *__restrict__ tile,
+                                              const bool detect, const int pmax, const uint32_t acc_lo, const uint32_t acc_hi,
+                                              uint2 *__restrict__ cells, const uint32_t cell_cap, const uint32_t base) {
+    constexpr int TAGH = STRICT ? 0 : 2;
+    uint32_t cnt = 0;
+    const uint32_t c_lo = P.B * k_stripe;
+    const uint32_t subW = 4u * P.g + (STRICT ? (uint32_t)-2 : 2u), subN = 4u * P.g + (STRICT ? (uint32_t)-1 : 1u);
+    const int target = 4 * pmax + TAGH;
+    int q[TF_BR];
+    TfReplayState S;
+#pragma unroll
+    for (int kk = 0; kk < TF_BR; ++kk) {
+        const uint32_t c = c_lo + TF_BR * lane + (uint32_t)kk;
+        q[kk] = tf_profile(P.ref_b[c < P.n ? c : 0u], c < P.n, P.match, P.mismatch);
+        S.Hs[kk] = TAGH; S.hpN[kk] = 0; S.dw[kk] = 0;
+    }
+    S.nwL = TAGH; S.wlast = 0; S.oh = 0; S.gmax = 0;
+    const uint32_t T = (P.m + 63u + 15u) & ~15u;
+    const uint32_t *__restrict__ ckcol = P.ck + (k_stripe ? k_stripe - 1u : 0u);
+    for (uint32_t t0 = 0; t0 < T; t0 += 64u) {
+        const uint32_t idx = t0 + 63u - lane;
+        S.Q = idx < P.m ? (int)(4u << (P.read_b[idx] & 28u)) : 0;        // one-hot nibble 4: the dot product yields 4 s
+        S.Bq = TAGH;                                                     // left boundary column, H(i, c_lo - 1) in stored form
+        if (k_stripe && idx < P.m) S.Bq = (int)(4u * tf_ld_l2(ckcol + (size_t)(idx + k_stripe - 1u) * WAVE)) + TAGH;
+        const uint32_t tend = T - t0 < 64u ? T - t0 : 64u;               // (a multiple of 16)
+        for (uint32_t r0 = 0; r0 < tend; r0 += 16u) {
+            const TfReplayState S0 = S;
+            S.gmax = 0;
+            cnt = tf_replay_group<STRICT, false>(S, q, subW, subN, t0 + r0, lane, P, c_lo, target, acc_lo, acc_hi, cells, cell_cap, base, cnt);
+            if (detect && BALLOT(S.gmax == target)) {                    // rare: a maximum cell in this group -- once more, listing
+                S = S0;
+                cnt = tf_replay_group<STRICT, true>(S, q, subW, subN, t0 + r0, lane, P, c_lo, target, acc_lo, acc_hi, cells, cell_cap, base, cnt);
+            }
+#pragma unroll
+            for (int kk = 0; kk < TF_BR; ++kk) tile[(((t0 + r0) >> 4) * TF_BR + (uint32_t)kk) * WAVE + lane] = S.dw[kk];
+        }
+    }
+    return cnt;
+}
+
+__device__ __forceinline__ int tf_sweep_dispatch(const TfPair &P, uint32_t lane, int &lm) {
+    switch (P.B) {
+#define TF_CASE(b) case b: return tf_sweep<b>(P, lane, lm);
+        TF_CASE(2) TF_CASE(4) TF_CASE(6) TF_CASE(8) TF_CASE(10) TF_CASE(12) TF_CASE(14) TF_CASE(16) TF_CASE(18) TF_CASE(20)
+        TF_CASE(22) TF_CASE(24) TF_CASE(26) TF_CASE(28) TF_CASE(30) TF_CASE(32) TF_CASE(34) TF_CASE(36) TF_CASE(38) TF_CASE(40)
+#undef TF_CASE
+    }
+    lm = 0;
+    return 0;
+}
+
+// ---- workgroup-shared state (LDS) ------------------------------------------------------------------------------------
+// The 4 wavefronts of a workgroup sweep 4 pairs, one each.  What follows the sweep comes in BLOCK TASKS -- one candidate
+// block of one pair: re-sweep it, list its maximum cells, walk their alignments, emit their records -- and any wavefront of
+// the workgroup takes any task: a pair whose tied maxima lie in several blocks (5 % of the headline's pairs) would otherwise
+// make its wavefront, and with one wavefront per SIMD the whole launch, last twice as long as the others.
+#define TF_QCAP 60u
+struct TfSlot {                      // one per wavefront = per pair of the workgroup
+    uint32_t n, m, out_id, pmax;
+    uint32_t ck_lo, ck_hi;           // the pair's column checkpoints
+    uint32_t tasks_total, tasks_done, cells;
+    uint32_t pad[7];
+};
+struct TfShared {
+    uint32_t q_n, q_taken, owners_done, pad;
+    uint32_t q[TF_QCAP];             // slot << 28 | first stripe of the block (kd) << 14 ... see tf_task_pack
+    uint32_t q_hi[TF_QCAP];          // accepted columns end (exclusive)
+    uint32_t q_lo[TF_QCAP];          // accepted columns start
+    TfSlot slot[TF_WAVES];
+};
+static_assert(sizeof(TfShared) / 4u <= WAVE * TF_WAVES, "the workgroup zeroes TfShared with one store per thread");
+
+__device__ __forceinline__ uint32_t tf_lds_add(uint32_t *p, uint32_t v) {
+    return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ uint32_t tf_lds_load(const uint32_t *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// One block task, by any wavefront `lane`s of the workgroup, in its own LDS region `lds`; the pair's codes are in the
+// region of the wavefront that swept it.
+template <bool STRICT>
+__device__ __forceinline__ void tf_block_task(const TraceArgs &A, const TFusedArgs &X, TfSlot *__restrict__ slot, const TfPair &P,
+                                              const uint32_t kd, const uint32_t acc_lo, const uint32_t acc_hi,
+                                              const uint32_t lane, uint32_t *__restrict__ lds) {
+    // LDS of this wavefront (dwords): tile | cells [2 cap] | ops [cap][ops_words] | staged ops of one alignment, one per byte |
+    //                                 reference codes | read codes
+    uint32_t *tile = lds;
+    uint2 *cells = reinterpret_cast<uint2 *>(lds + X.tile_words);
+    uint32_t *opsb = lds + X.tile_words + 2u * X.cell_cap;
+    uint32_t *stage = opsb + X.cell_cap * X.ops_words;
+    uint8_t *stage_b = reinterpret_cast<uint8_t *>(stage);
+    const uint32_t *tile_w = tile;
+    const int pmax = (int)slot->pmax;
+    const uint32_t out_id = slot->out_id;
+    const uint32_t umat = (uint32_t)A.match, umis = (uint32_t)A.mismatch, ugap = (uint32_t)A.gap;
+    const uint32_t max_ops = 16u * X.ops_words;
+    const uint32_t cap = X.cell_cap;
+    uint32_t total = 0;
+    // a block with more maximum cells than the list holds is taken `cap` cells at a time (each pass re-sweeps it)
+    for (uint32_t base = 0;; base += cap) {
+        WAVE_SYNC();
+        const uint32_t found = tf_replay<STRICT>(P, lane, kd, tile, true, pmax, acc_lo, acc_hi, cells, cap, base);
+        WAVE_SYNC();
+        total = found;
+        const uint32_t here = found > base ? (found - base < cap ? found - base : cap) : 0u;
+        uint32_t t_lo = P.B * kd;
+        uint32_t my_nops = 0, my_i = 0, my_j = 0;                          // lane a: header of alignment a of this pass
+        int my_begin = 0;
+        bool too_long = false;
+        // One alignment at a time, the whole wavefront on it: lane k looks at cell (i - k, j - k), the diagonal up-left of the
+        // current cell.  The leading lanes whose cell says "alignment" are one run of the path; a prefix sum of their score
+        // deltas finds where `while (score > 0)` (SmithWaterman.java:380) ends it.  The lane behind the run holds the gap move
+        // that follows.  One iteration per gap of the alignment instead of one per step.
+        for (uint32_t a = 0; a < here; ++a) {
+            const uint2 c0 = cells[a];
+            uint32_t i = tf_uni(c0.x), j = tf_uni(c0.y), score = (uint32_t)pmax, nops = 0;
+            int begin = 0;
+            for (uint32_t guard = 0;; ++guard) {
+                if (guard > 8192u) { too_long = true; break; }          // (a corrupted workspace must not hang the wavefront)
+                if (j - 1u < t_lo || j - 1u >= t_lo + TF_BW) {            // the block that holds column j - 1, right-aligned on it
+                    const uint32_t k2 = j > TF_BW ? (j - TF_BW + P.B - 1u) / P.B : 0u;
+                    WAVE_SYNC();
+                    (void)tf_replay<STRICT>(P, lane, k2, tile, false, pmax, 0u, 0u, cells, 0u, 0u);
+                    WAVE_SYNC();
+                    t_lo = P.B * k2;
+                }
+                const bool valid = lane < i && lane < j && j - 1u - lane >= t_lo;
+                const uint32_t col = valid ? j - 1u - lane : t_lo, row = valid ? i - 1u - lane : 0u;
+                const uint32_t c = col - t_lo, la = c / TF_BR, kk = c - la * TF_BR, t = row + la;
+                const uint32_t dwv = tile_w[((t >> 4) * TF_BR + kk) * WAVE + la];
+                const uint32_t rc = P.ref_b[col], qc = P.read_b[row];
+                const uint32_t tag = (dwv >> (2u * (t & 15u))) & 3u;
+                const uint32_t op = STRICT ? 2u - tag : tag;             // SWMI_DIR_D 0, SWMI_DIR_I 1, SWMI_DIR_A 2
+                const bool isA = valid && op == SWMI_DIR_A;
+                const uint32_t cum = tf_scan_add(isA ? (rc == qc ? umat : umis) : 0u);   // SmithWaterman.java:388-406, H(pred) = H - delta
+                const uint64_t runm = ~BALLOT(isA);
+                const uint32_t r = runm ? (uint32_t)__builtin_ctzll(runm) : 64u;
+                const uint64_t inrun = r >= 64u ? ~0ull : ((1ull << r) - 1ull);
+                const uint64_t stopm = BALLOT((int)(score - cum) <= 0) & inrun;
+                const uint32_t r_eff = stopm ? (uint32_t)__builtin_ctzll(stopm) + 1u : r;
+                if (lane < r_eff && nops + lane < 4u * X.stage_words) stage_b[nops + lane] = (uint8_t)SWMI_DIR_A;
+                if (r_eff) {
+                    score -= (uint32_t)__builtin_amdgcn_readlane((int)cum, (int)(r_eff - 1u));
+                    nops += r_eff; i -= r_eff; j -= r_eff;
+                    begin = (int)(j + 1u);                               // SmithWaterman.java:383: the column of the last visited cell
+                }
+                if (stopm || (int)score <= 0 || i == 0u || j == 0u) break;       // `while (score > 0)` :380
+                if (r < 64u && __builtin_amdgcn_readlane((int)valid, (int)r)) {  // the gap move behind the run
+                    const uint32_t opg = (uint32_t)__builtin_amdgcn_readlane((int)op, (int)r);
+                    if (lane == 0 && nops < 4u * X.stage_words) stage_b[nops] = (uint8_t)opg;
+                    ++nops;
+                    begin = (int)j;
+                    score -= ugap;
+                    if (opg == SWMI_DIR_I) --i; else --j;
+                    if ((int)score <= 0 || i == 0u || j == 0u) break;
+                }
+            }
+            WAVE_SYNC();
+            // pack the staged ops (one per byte) into alignment a's slot, 16 per dword
+            if (nops <= max_ops) {
+                uint32_t *dst = opsb + a * X.ops_words;
+                for (uint32_t w = lane; w < (nops + 15u) / 16u; w += WAVE) {
+                    uint32_t v = 0;
+#pragma unroll
+                    for (uint32_t x = 0; x < 4u; ++x) {
+                        const uint32_t by = stage[4u * w + x];
+                        v |= ((by & 3u) | ((by >> 6) & 0xCu) | ((by >> 12) & 0x30u) | ((by >> 18) & 0xC0u)) << (8u * x);
+                    }
+                    const uint32_t rem = nops - 16u * w;
+                    if (rem < 16u) v &= (1u << (2u * rem)) - 1u;
+                    dst[w] = v;
+                }
+            } else too_long = true;
+            if (lane == a) { my_nops = nops; my_begin = begin; my_i = c0.x; my_j = c0.y; }
+            WAVE_SYNC();
+        }
+        // records of this pass: header + packed ops, contiguous for the whole wave
+        if (here) {
+            const bool mine = lane < here;
+            const uint32_t opw = (my_nops + 15u) / 16u;
+            const uint32_t words = mine ? SWMI_ALNREC_WORDS + opw : 0u;
+            const uint32_t incl = tf_scan_add(words);
+            const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            unsigned long long off = 0;
+            if (lane == 0) off = atomicAdd(&A.hdr->used_words, (unsigned long long)tot);
+            off = ((unsigned long long)tf_uni((uint32_t)(off >> 32)) << 32) | tf_uni((uint32_t)off);
+            if (off + tot <= A.arena_cap_words && !too_long) {
+                if (mine) {
+                    uint32_t *dst = A.arena + off + (incl - words);
+                    const uint32_t *src = opsb + lane * X.ops_words;
+                    dst[0] = out_id; dst[1] = SWMI_RANK_BY_CELL; dst[2] = (uint32_t)my_begin;
+                    dst[3] = my_i; dst[4] = my_j; dst[5] = my_nops;
+                    for (uint32_t w = 0; w < opw; ++w) dst[SWMI_ALNREC_WORDS + w] = src[w];
+                }
+            } else if (lane == 0) {
+                atomicOr(&A.out[out_id].flags, SWMI_F_ARENA_OVF);
+                if (A.ovf_host) *A.ovf_host = 1u;
+            }
+        }
+        if (found <= base + cap) break;
+    }
+    // the pair's count; whoever finishes the pair's last task writes its output
+    if (lane == 0) {
+        tf_lds_add(&slot->cells, total);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        const uint32_t done = tf_lds_add(&slot->tasks_done, 1u) + 1u;
+        if (done == tf_lds_load(&slot->tasks_total)) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            PairOut po;
+            po.score = pmax; po.n_cells = tf_lds_load(&slot->cells);
+            po.flags = SWMI_F_DONE | (atomicOr(&A.out[out_id].flags, 0u) & SWMI_F_ARENA_OVF);
+            A.out[out_id].score = po.score; A.out[out_id].n_cells = po.n_cells; atomicOr(&A.out[out_id].flags, SWMI_F_DONE);
+            if (A.out_host) A.out_host[out_id] = po;
+        }
+    }
+}
+
+template <bool STRICT>
+__device__ __forceinline__ void tf_workgroup(const TraceArgs &A, const TFusedArgs &X, const uint32_t wave, const uint32_t lane,
+                                             uint32_t *__restrict__ lds_all) {
+    TfShared *sh = reinterpret_cast<TfShared *>(lds_all);
+    uint32_t *regions = lds_all + (sizeof(TfShared) + 3u) / 4u;
+    uint32_t *lds = regions + wave * X.lds_words;
+    const uint32_t region_codes = X.tile_words + 2u * X.cell_cap + X.cell_cap * X.ops_words + X.stage_words;   // reference codes | read codes
+    if (threadIdx.x < sizeof(TfShared) / 4u) lds_all[threadIdx.x] = 0u;
+    __syncthreads();
+#define TF_MARK(v) do { if (X.debug_marks && A.ovf_host && lane == 0 && blockIdx.x == 0) *(volatile uint32_t *)&A.ovf_host[2u + wave] = (v); } while (0)
+    TF_MARK(0x100u);
+    const uint32_t item = blockIdx.x * TF_WAVES + wave;
+    TfSlot *myslot = &sh->slot[wave];
+    const uint32_t g = (uint32_t)(-(int64_t)A.gap);
+
+    // ---- A: this wavefront's own pair -------------------------------------------------------------------------------------
+    if (item < X.n_items) {
+        const PairDesc pd = A.pairs[X.items[item]];
+        const SeqDesc rd = A.refs[pd.ref_id];
+        const SeqDesc qd = A.reads[pd.read_id];
+        const uint32_t n = rd.len, m = qd.len;
+        const uint32_t *__restrict__ refw = A.seqw + rd.boff;
+        const uint32_t *__restrict__ readw = A.seqw + qd.boff;
+        uint32_t *refc = lds + region_codes;
+        uint32_t *readc = refc + X.ref_words;
+        for (uint32_t w = lane; w < (n + 3u) / 4u; w += WAVE) refc[w] = refw[w];
+        for (uint32_t w = lane; w < (m + 3u) / 4u; w += WAVE) readc[w] = readw[w];
+        WAVE_SYNC();
+        TfPair P;
+        P.n = n; P.m = m;
+        P.B = swmi_tf_cols_per_lane(n);
+        P.L = (n + P.B - 1u) / P.B;
+        P.ref_b = reinterpret_cast<const uint8_t *>(refc);
+        P.read_b = reinterpret_cast<const uint8_t *>(readc);
+        P.ck = const_cast<uint32_t *>(A.dir) + pd.dir_off;
+        P.match = A.match; P.mismatch = A.mismatch;
+        P.g = g;
+        int lane_max = 0;
+        const int pmax = tf_sweep_dispatch(P, lane, lane_max);
+        TF_MARK(0x200u);
+        if (pmax <= 0) {                                                   // every cell ties at 0: SmithWaterman.java:154,182-185
+            PairOut po;
+            po.score = 0; po.flags = SWMI_F_DEGENERATE | SWMI_F_DONE; po.n_cells = (uint64_t)m * n;
+            if (lane == 0) { A.out[pd.out_id] = po; if (A.out_host) A.out_host[pd.out_id] = po; }
+        } else {
+            // candidate stripes, right to left, grouped into blocks: block tasks for the workgroup's queue
+            uint64_t cand = BALLOT(lane_max == pmax && lane < P.L);
+            uint32_t acc_top = n, ntask = 0, kd_list[12], hi_list[12];
+            while (cand && ntask < 12u) {
+                const uint32_t ls = 63u - (uint32_t)__builtin_clzll(cand);
+                const uint32_t s_end = P.B * (ls + 1u);
+                const uint32_t kd = s_end > TF_BW ? (s_end - TF_BW + P.B - 1u) / P.B : 0u;
+                kd_list[ntask] = kd; hi_list[ntask] = s_end < acc_top ? s_end : acc_top;
+                ++ntask;
+                acc_top = P.B * kd;
+                cand &= kd ? ((1ull << kd) - 1ull) : 0ull;
+            }
+            if (lane == 0) {
+                if (A.out) { PairOut po; po.score = pmax; po.flags = 0u; po.n_cells = 0; A.out[pd.out_id] = po; }
+                myslot->n = n; myslot->m = m; myslot->out_id = pd.out_id; myslot->pmax = (uint32_t)pmax;
+                const unsigned long long cka = (unsigned long long)(uintptr_t)P.ck;
+                myslot->ck_lo = (uint32_t)cka; myslot->ck_hi = (uint32_t)(cka >> 32);
+                myslot->tasks_total = ntask;
+            }
+            // the checkpoints are read back by other lanes and wavefronts of this workgroup: stores done, loads through L2
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            // append under a tiny spin lock (at most 4 contenders, once per pair); the count moves after the entries are written
+            if (lane == 0) {
+                for (uint32_t spins = 0; __hip_atomic_exchange(&sh->pad, 1u, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u; ++spins) {
+                    if (spins > (1u << 22)) { if (A.ovf_host) A.ovf_host[1] = 0xDEAD0001u; break; }      // (never seen: a wavefront must not hang)
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                uint32_t at = tf_lds_load(&sh->q_n);
+                for (uint32_t x = 0; x < ntask && at < TF_QCAP; ++x, ++at) {
+                    sh->q[at] = (wave << 28) | kd_list[x];
+                    sh->q_hi[at] = hi_list[x];
+                    sh->q_lo[at] = P.B * kd_list[x];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __hip_atomic_store(&sh->q_n, at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_store(&sh->pad, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    }
+    TF_MARK(0x300u);
+    if (lane == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        tf_lds_add(&sh->owners_done, 1u);
+    }
+
+    // ---- B + C: block tasks, any pair of the workgroup ----------------------------------------------------------------------
+    for (;;) {
+        uint32_t idx = 0;
+        if (lane == 0) idx = tf_lds_add(&sh->q_taken, 1u);
+        idx = tf_uni(idx);
+        TF_MARK(0x400u | idx);
+        bool have = false;
+        for (uint32_t spins = 0;; ++spins) {
+            if (spins > (1u << 22)) { if (lane == 0 && A.ovf_host) A.ovf_host[1] = 0xDEAD0002u; break; }    // (never seen: a wavefront must not hang)
+            const uint32_t qn = tf_lds_load(&sh->q_n);
+            if (idx < qn) { have = true; break; }
+            if (tf_lds_load(&sh->owners_done) >= TF_WAVES) {
+                if (idx < tf_lds_load(&sh->q_n)) { have = true; }
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+        if (!have) break;
+        TF_MARK(0x500u | idx);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const uint32_t e = tf_uni(sh->q[idx]), acc_hi = tf_uni(sh->q_hi[idx]), acc_lo = tf_uni(sh->q_lo[idx]);
+        const uint32_t sw = e >> 28, kd = e & 0x0FFFFFFFu;
+        TfSlot *slot = &sh->slot[sw];
+        TfPair P;
+        P.n = tf_uni(slot->n); P.m = tf_uni(slot->m);
+        P.B = swmi_tf_cols_per_lane(P.n);
+        P.L = (P.n + P.B - 1u) / P.B;
+        uint32_t *codes = regions + sw * X.lds_words + region_codes;
+        P.ref_b = reinterpret_cast<const uint8_t *>(codes);
+        P.read_b = reinterpret_cast<const uint8_t *>(codes + X.ref_words);
+        P.ck = reinterpret_cast<uint32_t *>((uintptr_t)(((unsigned long long)tf_uni(slot->ck_hi) << 32) | tf_uni(slot->ck_lo)));
+        P.match = A.match; P.mismatch = A.mismatch;
+        P.g = g;
+        tf_block_task<STRICT>(A, X, slot, P, kd, acc_lo, acc_hi, lane, lds);
+        TF_MARK(0x600u | idx);
+    }
+    TF_MARK(0x700u);
+}
+
+}  // namespace
+
+extern "C" __global__ void __launch_bounds__(WAVE * TF_WAVES)
+sw_tfused_kernel(const TraceArgs A, const TFusedArgs X) {
+    extern __shared__ uint32_t tf_lds[];
+    const uint32_t wave = tf_uni(threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (A.strict) tf_workgroup<true>(A, X, wave, lane, tf_lds);
+    else          tf_workgroup<false>(A, X, wave, lane, tf_lds);
+}
+
+extern "C" hipError_t swmi_launch_tfused(const TraceArgs *a, const TFusedArgs *x, hipStream_t st) {
+    if (x->n_items == 0) return hipSuccess;
+    static const bool attr = [] { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(sw_tfused_kernel),
+                                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); return true; }();
+    (void)attr;
+    const uint32_t groups = (x->n_items + TF_WAVES - 1) / TF_WAVES;
+    size_t lds = (size_t)TF_WAVES * x->lds_words * sizeof(uint32_t) + ((sizeof(TfShared) + 3u) / 4u) * 4u;
+    // a launch that fits the chip once: an LDS request that keeps the dispatcher from stacking workgroups on some CUs while
+    // others stay empty (swmi_kernels.hip, spread_lds)
+    static const int spread = getenv("SWMI_LDS_SPREAD") ? atoi(getenv("SWMI_LDS_SPREAD")) : 1;
+    if (spread && groups <= 4u * 256u) {
+        const size_t even = ((size_t)(160u * 1024u) / ((groups + 255u) / 256u)) & ~(size_t)1023;
+        if (even > lds) lds = even;
+    }
+    hipLaunchKernelGGL(sw_tfused_kernel, dim3(groups), dim3(WAVE * TF_WAVES), lds, st, *a, *x);
+    return hipGetLastError();
+}

@@ -19,21 +19,24 @@ READ_80 = "AATTTTAGTCTCTCCCTACCCTTTTGGACAGAGCTTCCTGTCCTCTCATTTCACAGGTTATGCAACAGA
 READ_20 = "ACTGACTGACTGACTGACTG"   # EngineerData.java:29
 
 
-@pytest.fixture(scope="module", params=[(1, 1, 0, 0), (2, 1, 0, 0), (0, 1, 0, 0), (1, 0, 0, 0), (-1, 1, -1, -1), (1, 1, 1, 0), (1, 0, 1, 0),
-                                        (1, 1, 0, 1), (1, 0, -1, 1)],
+@pytest.fixture(scope="module", params=[(1, 1, 0, 0, 0), (2, 1, 0, 0, 0), (0, 1, 0, 0, 0), (1, 0, 0, 0, 0), (-1, 1, -1, -1, -1), (1, 1, 1, 0, 0),
+                                        (1, 0, 1, 0, 0), (1, 1, 0, 1, 0), (1, 0, -1, 1, 0), (1, 1, 0, 0, 1), (1, 0, -1, -1, 1)],
                 ids=["mode1-winmax", "mode2-events", "mode0-field", "mode1-d2h-copy", "automatic", "mode1-split-traceback",
-                     "mode1-split-d2h-copy", "mode1-resident", "mode1-resident-d2h-copy"])
+                     "mode1-split-d2h-copy", "mode1-resident", "mode1-resident-d2h-copy", "mode1-tfused", "mode1-tfused-d2h-copy"])
 def ctx(request):
     """Every kernel pipeline (include/swmi.h, swmi_set_option "mode"), results written straight to pinned host
     memory or fetched by a copy, the mode-1 traceback with one workgroup per pair or split per window / alignment
     (option "tb_split"), small pairs handled whole by one wavefront with the direction field in LDS (option "resident":
-    0 never, 1 wherever it fits); -1 lets the library choose."""
+    0 never, 1 wherever it fits), the usual pair swept in the transposed layout and traced back by the same wavefront
+    (option "tfused": 0 never, 1 every pair that qualifies); -1 lets the library choose."""
     c = sw.Context(0)
     c.set_option("mode", request.param[0])
     c.set_option("zero_copy", request.param[1])
     c.set_option("tb_split", request.param[2])
     c.set_option("resident", request.param[3])
+    c.set_option("tfused", request.param[4])
     c.test_resident = request.param[3]
+    c.test_tfused = request.param[4]
     yield c
     c.close()
 
