@@ -49,6 +49,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--d2h-copy", action="store_true", help="fetch results with a D2H copy instead of zero-copy writes to pinned memory")
     ap.add_argument("--col-chunks", type=int, default=None, help="column chunks per pair (include/swmi.h): 0 automatic, 1 never, N force")
+    ap.add_argument("--tfused", type=int, default=None, help="transposed fused kernel (include/swmi.h): -1 automatic, 0 never, 1 every pair that qualifies")
     ap.add_argument("--mode", type=int, default=None, help="kernel pipeline (include/swmi.h): 1 default, 2 event-tracked maxima, 0 HBM direction field")
     return ap.parse_args()
 
@@ -159,6 +160,8 @@ def main():
         ctx.set_option("mode", args.mode)
     if args.col_chunks is not None:
         ctx.set_option("col_chunks", args.col_chunks)
+    if args.tfused is not None:
+        ctx.set_option("tfused", args.tfused)
     if args.d2h_copy:
         ctx.set_option("zero_copy", 0)
     batch = ctx.upload(refs, reads)          # H2D happens here, outside the timed region

@@ -100,10 +100,10 @@ void        swmi_default_params(swmi_params *p);
  *                (80 bp reads x 400 bp references, the reference's EngineerData shapes) are handled start to finish by one
  *                wavefront -- two sweeps inside LDS, all alignments walked at once, one per lane; 0 never; 1 whenever the
  *                field fits 40 KB.
- * tfused: -1 (default) in launches of >= 256 pairs, the usual pair -- fast symbols on both sides, scores within int4, gap < 0,
- *                a read of at most 256 bases, a reference of at most 2560 -- is swept in the TRANSPOSED layout (reference
- *                columns on the lanes, the read streaming through) and traced back by the same wavefront in the same
- *                launch (sw_tfused_kernel); 0 never; 1 in launches of any size.
+ * tfused: 1: the usual pair -- fast symbols on both sides, scores within int4, gap < 0, a read of at most 256 bases, a reference
+ *                of at most 2560 -- is swept in the TRANSPOSED layout (reference columns on the lanes, the read streaming
+ *                through) and traced back in the same launch (sw_tfused_kernel: block tasks and walk items shared by the
+ *                wavefronts of a workgroup); 0 or -1 (default): never -- measured slower than the two-kernel pipeline.
  * Further knobs: spin_us (how long a run polls its stream before it blocks, default 2000); col_chunks (0 automatic,
  * 1 never, N > 1 force up to N column chunks per pair: a launch of few pairs with long references is swept by several
  * wavefronts per pair); debug_strip_spins / debug_reverse_strips (tests of the strip pipeline's give-up path). */

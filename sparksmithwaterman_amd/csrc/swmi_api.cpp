@@ -619,9 +619,11 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
                         res_need_words(m_, n_, opw) * 4 <= (ctx->resident == 1 ? 40u : 20u) * 1024u;
         }
     // Transposed, fused pairs (swmi_tfused.hip): reference columns on the lanes, the read streaming through, sweep AND
-    // traceback by one wavefront in one launch -- for the usual pair (fast symbols, int4 scores, gap < 0, read <= 256,
-    // reference <= 2560).  A launch of few pairs is latency-bound and keeps the several-wavefronts-per-pair paths.
-    const bool tf_possible = b->eff_mode == 1 && !cells_exact && ctx->tfused != 0 && (ctx->tfused == 1 || np >= 256) &&
+    // traceback in one launch -- for the usual pair (fast symbols, int4 scores, gap < 0, read <= 256, reference <= 2560).
+    // Its sweep needs 20 % fewer instructions, but its traceback (one wavefront per block of a pair) does not beat the
+    // workgroup-per-pair kernel: measured 0.170 ms against 0.088 + 0.071 at the headline, and slower for big batches (LDS and
+    // registers hold it to one or two wavefronts per SIMD).  Kept as an option, tested in every GPU parity test; not chosen.
+    const bool tf_possible = b->eff_mode == 1 && !cells_exact && ctx->tfused == 1 &&      // (-1, automatic: not chosen -- DESIGN.md 4.4)
                              P.match > 0 && P.match <= 7 && P.mismatch >= -8 && P.mismatch <= P.match && P.gap < 0 && P.gap >= -64;
     if ((cols_possible || res_maybe || tf_possible) && !b->acgt_known) {
         // the fast-symbol flags are derived on the device by the encode kernel
@@ -887,13 +889,20 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
         xt.stage_words = (tf_max_path + 3u) / 4u + 1u;
         static const bool tf_marks = getenv("SWMI_DEBUG_MARKS") != nullptr;
         xt.debug_marks = tf_marks ? 1u : 0u;
-        xt.lds_words = (xt.tile_words + 2u * xt.cell_cap + xt.cell_cap * xt.ops_words + xt.stage_words + xt.ref_words + xt.read_words + 3u) & ~3u;
+        xt.lds_words = (xt.tile_words + 2u * xt.cell_cap + xt.stage_words + xt.ref_words + xt.read_words + 3u) & ~3u;
+        {   // helper wavefronts while their LDS regions fit beside the four sweepers' (160 KB per workgroup)
+            static const int tf_helpers = getenv("SWMI_TF_HELPERS") ? atoi(getenv("SWMI_TF_HELPERS")) : 2;
+            const uint64_t region = 4ull * xt.lds_words, budget = 156ull * 1024;      // (160 KB less the workgroup's queues)
+            const uint64_t left = budget > 4 * region ? budget - 4 * region : 0;
+            xt.n_helpers = (uint32_t)std::min<uint64_t>((uint64_t)std::max(0, std::min(tf_helpers, 2)), region ? left / region : 0);
+        }
         const bool zc = ctx->zero_copy != 0;
         if (zc) {
             // results land in pinned host memory while the kernel runs: [overflow word .. | PairOut x np | arena]
             if ((rc = b->h_result.reserve(a_off + arena_cap * 4))) return rc;
             uint8_t *hd = (uint8_t *)b->h_result.dp;
             *(volatile uint32_t *)b->h_result.p = 0u;
+            ((volatile uint32_t *)b->h_result.p)[1] = 0u;
             ta.ovf_host = (uint32_t *)hd;
             ta.out_host = (PairOut *)(hd + result_out_off());
             ta.arena = (uint32_t *)(hd + a_off);
@@ -977,6 +986,11 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
             if (q != hipSuccess) HIP_TRY(hipStreamSynchronize(ctx->stream));
         }
         const auto c2 = std::chrono::steady_clock::now();
+        if (zc && ((const volatile uint32_t *)b->h_result.p)[1] != 0u) {      // sw_tfused_kernel gave up a wait that cannot last (never seen)
+            const uint32_t code = ((const volatile uint32_t *)b->h_result.p)[1];
+            ((volatile uint32_t *)b->h_result.p)[1] = 0u;
+            return fail(SWMI_ERR_HIP, "sw_tfused_kernel: internal wait abandoned (code %08x); results discarded", code);
+        }
         if (*(volatile uint32_t *)ctx->h_err.p != 0u) {
             // a strip of the pipelined sweep gave up waiting for its producer wavefront (it was not dispatched, or did not
             // move for the whole spin budget): nothing of this launch is used.  The chunk is swept again with ONE wavefront
@@ -1005,7 +1019,7 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
                     t0 += d[4*k]; t1 += d[4*k+1] & 0xFFFFFFFFull; t2 += d[4*k+1] >> 32; t3 += d[4*k+2] >> 16; t4 += d[4*k+3] >> 32; t5 += d[4*k+3] & 0xFFFFFFFFull;
                     mx = std::max(mx, d[4*k]);
                 }
-                fprintf(stderr, "[swmi tfused dbg] ticks per pair: total mean=%.0f max=%llu = prologue %.0f + sweep %.0f + block re-sweeps %.0f (%.2f per pair) + walks %.0f + rest %.0f\n",
+                fprintf(stderr, "[swmi tfused dbg] ticks per sweeper wavefront: lifetime mean=%.0f max=%llu = prologue %.0f + sweep %.0f + first block task %.0f (%.2f block tasks per wavefront) + waiting for tasks %.0f + rest (more tasks, walk items) %.0f\n",
                         t0 / np, mx, t2 / np, t1 / np, t3 / np, t5 / np, t4 / np, (t0 - t1 - t2 - t3 - t4) / np);
             }
             double a0 = 0, a1 = 0, a2 = 0, a3 = 0; unsigned long long mx = 0;

@@ -186,7 +186,7 @@ struct TFusedArgs {
     uint32_t        read_words;  // ... and the longest read's
     uint32_t        stage_words; // LDS dwords for the ops of ONE alignment staged one per byte (the longest possible path)
     uint32_t        debug_marks; // diagnostics: workgroup 0 leaves progress marks in the host-mapped result header
-    uint32_t        pad;
+    uint32_t        n_helpers;   // wavefronts per workgroup (0..2) beyond the four that sweep: they only take block tasks
 };
 #define SWMI_TF_BMAX   40u          // columns per lane of the transposed sweep: references up to 64 * 40 = 2560 bases
 #define SWMI_TF_BR     5u           // columns per lane of a re-swept block (320 columns: a 150 bp read's path fits with room)

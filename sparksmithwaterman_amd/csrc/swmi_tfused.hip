@@ -36,7 +36,8 @@
 #include "swmi_device.h"
 
 #define WAVE 64
-#define TF_WAVES 4
+#define TF_WAVES 4                       // wavefronts of a workgroup that sweep a pair each
+#define TF_HELPERS 2                     // ... and wavefronts that only take block tasks
 #define TF_BR SWMI_TF_BR                 // columns per lane of a re-swept block
 #define TF_BW (64u * TF_BR)              // ... and its width
 #define BALLOT(pred) __builtin_amdgcn_ballot_w64(pred)
@@ -95,14 +96,13 @@ __device__ __forceinline__ int tf_sweep(const TfPair &P, const uint32_t lane, in
         H[k] = 0; hp[k] = 0;
     }
     int nwL = 0, M = 0, oh = 0;
-    const uint32_t T = P.m + P.L - 1u;
-    uint32_t *__restrict__ ckp = P.ck + lane;
+    const uint32_t T = tf_uni(P.m + P.L - 1u);
+    uint32_t *__restrict__ ckrow = P.ck;                                  // (wave-uniform: the store takes it as its scalar base)
     for (uint32_t t0 = 0; t0 < T; t0 += 64u) {
         const uint32_t idx = t0 + 63u - lane;
         int Q = idx < P.m ? (int)(1u << (P.read_b[idx] & 28u)) : 0;       // lane 63 holds the symbol of step t0, lane 62 of t0 + 1, ...
         const uint32_t tend = T - t0 < 64u ? T - t0 : 64u;
-
-        for (uint32_t r = 0; r < tend; ++r) {
+        for (uint32_t r = 0; r < tend; ++r, ckrow += WAVE) {
             Q = tf_ror1(Q);
             oh = tf_shr1(Q, oh);                                       // the symbol moves one lane down; lane 0 takes the next one
             const int nw_next = tf_shr1_zero(H[B - 1]);                // lane l-1 finished this row one step ago: W's H now, NW next step
@@ -122,7 +122,7 @@ __device__ __forceinline__ int tf_sweep(const TfPair &P, const uint32_t lane, in
 #pragma unroll
             for (int k = 0; k + 1 < B; k += 2) M = tf_max3(M, H[k], H[k + 1]);
             if (B & 1) M = M > H[B - 1] ? M : H[B - 1];
-            ckp[(size_t)(t0 + r) * WAVE] = (uint32_t)H[B - 1];
+            ckrow[lane] = (uint32_t)H[B - 1];
         }
     }
     lane_max = M;
@@ -245,25 +245,34 @@ __device__ __forceinline__ int tf_sweep_dispatch(const TfPair &P, uint32_t lane,
 }
 
 // ---- workgroup-shared state (LDS) ------------------------------------------------------------------------------------
-// The 4 wavefronts of a workgroup sweep 4 pairs, one each.  What follows the sweep comes in BLOCK TASKS -- one candidate
-// block of one pair: re-sweep it, list its maximum cells, walk their alignments, emit their records -- and any wavefront of
-// the workgroup takes any task: a pair whose tied maxima lie in several blocks (5 % of the headline's pairs) would otherwise
-// make its wavefront, and with one wavefront per SIMD the whole launch, last twice as long as the others.
-#define TF_QCAP 60u
-struct TfSlot {                      // one per wavefront = per pair of the workgroup
+// The first 4 wavefronts of a workgroup sweep 4 pairs, one each.  What follows the sweep comes in TASKS any wavefront of the
+// workgroup may take -- the sweepers once their own pair is through, and up to two helper wavefronts that do nothing else:
+//   block task: one candidate block of one pair -- re-sweep it into the taker's tile, list its maximum cells, walk the first
+//               alignment, hand the others out as walk items;
+//   walk item:  one alignment, walked through the tile of the wavefront that listed it (LDS is shared), into a record.
+// With one wavefront per SIMD the launch lasts as long as its slowest pair: a pair with tied maxima in several blocks, or
+// three alignments to walk, must not be the work of one wavefront.
+#define TF_QCAP 96u
+struct TfSlot {                      // one per sweeper = per pair of the workgroup
     uint32_t n, m, out_id, pmax;
     uint32_t ck_lo, ck_hi;           // the pair's column checkpoints
     uint32_t tasks_total, tasks_done, cells;
     uint32_t pad[7];
 };
+struct TfQueue {
+    uint32_t n, taken, lock, pad;
+    uint4 e[TF_QCAP];
+};
 struct TfShared {
-    uint32_t q_n, q_taken, owners_done, pad;
-    uint32_t q[TF_QCAP];             // slot << 28 | first stripe of the block (kd) << 14 ... see tf_task_pack
-    uint32_t q_hi[TF_QCAP];          // accepted columns end (exclusive)
-    uint32_t q_lo[TF_QCAP];          // accepted columns start
+    uint32_t owners_done, pad[3];
+    uint32_t tile_users[8];          // walk items still reading this wavefront's tile
+    TfQueue qb;                      // block tasks {slot, first stripe, accepted columns lo, hi}: taken by the sweepers
+    TfQueue qw;                      // walk items {slot | tile owner << 8, t_lo, i, j}: taken by the helpers, and by sweepers with no block task left
     TfSlot slot[TF_WAVES];
 };
-static_assert(sizeof(TfShared) / 4u <= WAVE * TF_WAVES, "the workgroup zeroes TfShared with one store per thread");
+// Who waits for whom: a wavefront waits only for the walk items that read ITS tile (before it overwrites the tile).  Helpers
+// never list cells, so nobody reads their tiles and they never wait: every walk item is taken and finished in the end.
+
 
 __device__ __forceinline__ uint32_t tf_lds_add(uint32_t *p, uint32_t v) {
     return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -272,143 +281,212 @@ __device__ __forceinline__ uint32_t tf_lds_load(const uint32_t *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// One block task, by any wavefront `lane`s of the workgroup, in its own LDS region `lds`; the pair's codes are in the
-// region of the wavefront that swept it.
+// lane 0 appends to a queue of the workgroup: lock, write entries at tf_queue_at() + k, publish the new count
+__device__ __forceinline__ uint32_t tf_queue_lock(const TraceArgs &A, TfQueue *q) {
+    for (uint32_t spins = 0; __hip_atomic_exchange(&q->lock, 1u, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u; ++spins) {
+        if (spins > (1u << 22)) { if (A.ovf_host) A.ovf_host[1] = 0xDEAD0001u; break; }          // (never seen: a wavefront must not hang)
+        __builtin_amdgcn_s_sleep(1);
+    }
+    return tf_lds_load(&q->n);
+}
+__device__ __forceinline__ void tf_queue_publish(TfQueue *q, const uint32_t new_n) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __hip_atomic_store(&q->n, new_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // (the count moves after the entries are written)
+    __hip_atomic_store(&q->lock, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// The region of a wavefront (dwords): tile | cells [2 cap] | staged ops of one alignment, one per byte | reference codes | read codes
+struct TfRegion {
+    uint32_t *tile;
+    uint2 *cells;
+    uint32_t *stage;
+};
+__device__ __forceinline__ TfRegion tf_region(const TFusedArgs &X, uint32_t *lds) {
+    TfRegion R;
+    R.tile = lds;
+    R.cells = reinterpret_cast<uint2 *>(lds + X.tile_words);
+    R.stage = lds + X.tile_words + 2u * X.cell_cap;
+    return R;
+}
+
+// takes the next entry of a queue if there is one (lane 0 decides, all lanes get the index; 0xFFFFFFFF: none)
+__device__ __forceinline__ uint32_t tf_queue_try_take(TfQueue *q, const uint32_t lane) {
+    uint32_t idx = 0xFFFFFFFFu;
+    if (lane == 0) {
+        for (;;) {
+            uint32_t t = tf_lds_load(&q->taken);
+            if (t >= tf_lds_load(&q->n)) break;
+            if (__hip_atomic_compare_exchange_strong(&q->taken, &t, t + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) { idx = t; break; }
+        }
+    }
+    return tf_uni(idx);
+}
+
+// before a wavefront overwrites its own tile: the walk items reading it must be through
+__device__ __forceinline__ void tf_wait_tile(const TraceArgs &A, TfShared *sh, const uint32_t me) {
+    for (uint32_t spins = 0; tf_lds_load(&sh->tile_users[me]) != 0u; ++spins) {
+        if (spins > (1u << 22)) { if (A.ovf_host) A.ovf_host[1] = 0xDEAD0003u; break; }
+        __builtin_amdgcn_s_sleep(4);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// One alignment, the whole wavefront on it: lane k looks at cell (i - k, j - k), the diagonal up-left of the current cell.
+// The leading lanes whose cell says "alignment" are one run of the path; a prefix sum of their score deltas finds where
+// `while (score > 0)` (SmithWaterman.java:380) ends it.  The lane behind the run holds the gap move that follows: one
+// iteration per gap of the alignment instead of one per step.  The tile read is `tile_w` (columns t_lo ..), the walker's own
+// or the one of the wavefront that listed the cell (`foreign`: given back as soon as the walk leaves it); a walk that leaves
+// its block on the left re-sweeps the block it needs into the walker's own tile.  The record goes straight to the arena.
 template <bool STRICT>
-__device__ __forceinline__ void tf_block_task(const TraceArgs &A, const TFusedArgs &X, TfSlot *__restrict__ slot, const TfPair &P,
+__device__ __forceinline__ bool tf_walk(const TraceArgs &A, const TFusedArgs &X, TfShared *sh, const TfPair &P, const uint32_t out_id,
+                                        const int pmax, const uint32_t ci, const uint32_t cj, const uint32_t *tile_w, uint32_t t_lo,
+                                        int foreign, const uint32_t me, const uint32_t lane, const TfRegion &R) {
+    const uint32_t umat = (uint32_t)A.match, umis = (uint32_t)A.mismatch, ugap = (uint32_t)A.gap;
+    uint8_t *stage_b = reinterpret_cast<uint8_t *>(R.stage);
+    const uint32_t stage_cap = 4u * X.stage_words;
+    uint32_t i = ci, j = cj, score = (uint32_t)pmax, nops = 0;
+    int begin = 0;
+    bool bad = false, moved = false;
+    for (uint32_t guard = 0;; ++guard) {
+        if (guard > 8192u) { bad = true; break; }                        // (a corrupted workspace must not hang the wavefront)
+        if (j - 1u < t_lo || j - 1u >= t_lo + TF_BW) {                    // the block that holds column j - 1, right-aligned on it
+            const uint32_t k2 = j > TF_BW ? (j - TF_BW + P.B - 1u) / P.B : 0u;
+            if (foreign >= 0) {
+                if (lane == 0) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); tf_lds_add(&sh->tile_users[foreign], 0xFFFFFFFFu); }
+                foreign = -1;
+            }
+            tf_wait_tile(A, sh, me);
+            WAVE_SYNC();
+            (void)tf_replay<STRICT>(P, lane, k2, R.tile, false, pmax, 0u, 0u, R.cells, 0u, 0u);
+            WAVE_SYNC();
+            tile_w = R.tile;
+            t_lo = P.B * k2;
+            moved = true;
+        }
+        const bool valid = lane < i && lane < j && j - 1u - lane >= t_lo;
+        const uint32_t col = valid ? j - 1u - lane : t_lo, row = valid ? i - 1u - lane : 0u;
+        const uint32_t c = col - t_lo, la = c / TF_BR, kk = c - la * TF_BR, t = row + la;
+        const uint32_t dwv = tile_w[((t >> 4) * TF_BR + kk) * WAVE + la];
+        const uint32_t rc = P.ref_b[col], qc = P.read_b[row];
+        const uint32_t tag = (dwv >> (2u * (t & 15u))) & 3u;
+        const uint32_t op = STRICT ? 2u - tag : tag;                     // SWMI_DIR_D 0, SWMI_DIR_I 1, SWMI_DIR_A 2
+        const bool isA = valid && op == SWMI_DIR_A;
+        const uint32_t dlt = rc == qc ? umat : umis;                     // SmithWaterman.java:388-406, H(pred) = H - delta
+        const uint32_t cum = tf_scan_add(isA ? dlt : 0u);
+        const uint64_t runm = ~BALLOT(isA);
+        const uint32_t r = runm ? (uint32_t)__builtin_ctzll(runm) : 64u;
+        const uint64_t inrun = r >= 64u ? ~0ull : ((1ull << r) - 1ull);
+        const uint64_t stopm = BALLOT((int)(score - cum) <= 0) & inrun;
+        const uint32_t r_eff = stopm ? (uint32_t)__builtin_ctzll(stopm) + 1u : r;
+        if (lane < r_eff && nops + lane < stage_cap) stage_b[nops + lane] = (uint8_t)SWMI_DIR_A;
+        if (r_eff) {
+            score -= (uint32_t)__builtin_amdgcn_readlane((int)cum, (int)(r_eff - 1u));
+            nops += r_eff; i -= r_eff; j -= r_eff;
+            begin = (int)(j + 1u);                                       // SmithWaterman.java:383: the column of the last visited cell
+        }
+        if (stopm || (int)score <= 0 || i == 0u || j == 0u) break;       // `while (score > 0)` :380
+        if (r < 64u && __builtin_amdgcn_readlane((int)valid, (int)r)) {  // the gap move behind the run
+            const uint32_t opg = (uint32_t)__builtin_amdgcn_readlane((int)op, (int)r);
+            if (lane == 0 && nops < stage_cap) stage_b[nops] = (uint8_t)opg;
+            ++nops;
+            begin = (int)j;
+            score -= ugap;
+            if (opg == SWMI_DIR_I) --i; else --j;
+            if ((int)score <= 0 || i == 0u || j == 0u) break;
+        }
+    }
+    if (foreign >= 0 && lane == 0) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); tf_lds_add(&sh->tile_users[foreign], 0xFFFFFFFFu); }
+    WAVE_SYNC();
+    // the record: header + the staged ops (one per byte) packed 16 per dword
+    const uint32_t opw = (nops + 15u) / 16u, words = SWMI_ALNREC_WORDS + opw;
+    unsigned long long off = 0;
+    if (lane == 0) off = atomicAdd(&A.hdr->used_words, (unsigned long long)words);
+    off = ((unsigned long long)tf_uni((uint32_t)(off >> 32)) << 32) | tf_uni((uint32_t)off);
+    if (off + words <= A.arena_cap_words && !bad && nops <= stage_cap) {
+        uint32_t *dst = A.arena + off;
+        if (lane == 0) { dst[0] = out_id; dst[1] = SWMI_RANK_BY_CELL; dst[2] = (uint32_t)begin; dst[3] = ci; dst[4] = cj; dst[5] = nops; }
+        for (uint32_t w = lane; w < opw; w += WAVE) {
+            uint32_t v = 0;
+#pragma unroll
+            for (uint32_t x = 0; x < 4u; ++x) {
+                const uint32_t by = R.stage[4u * w + x];
+                v |= ((by & 3u) | ((by >> 6) & 0xCu) | ((by >> 12) & 0x30u) | ((by >> 18) & 0xC0u)) << (8u * x);
+            }
+            const uint32_t rem = nops - 16u * w;
+            if (rem < 16u) v &= (1u << (2u * rem)) - 1u;
+            dst[SWMI_ALNREC_WORDS + w] = v;
+        }
+    } else if (lane == 0) {
+        atomicOr(&A.out[out_id].flags, SWMI_F_ARENA_OVF);
+        if (A.ovf_host) *A.ovf_host = 1u;
+    }
+    WAVE_SYNC();
+    return moved;
+}
+
+// a task of pair `slot` is through: whoever finishes the pair's last task writes its output
+__device__ __forceinline__ void tf_task_done(const TraceArgs &A, TfSlot *slot, const uint32_t cells, const uint32_t lane) {
+    if (lane != 0) return;
+    if (cells) tf_lds_add(&slot->cells, cells);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    const uint32_t done = tf_lds_add(&slot->tasks_done, 1u) + 1u;
+    if (done == tf_lds_load(&slot->tasks_total)) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const uint32_t out_id = slot->out_id;
+        PairOut po;
+        po.score = (int)slot->pmax; po.n_cells = tf_lds_load(&slot->cells);
+        po.flags = SWMI_F_DONE | (atomicOr(&A.out[out_id].flags, 0u) & SWMI_F_ARENA_OVF);
+        A.out[out_id].score = po.score; A.out[out_id].n_cells = po.n_cells; atomicOr(&A.out[out_id].flags, SWMI_F_DONE);
+        if (A.out_host) A.out_host[out_id] = po;
+    }
+}
+
+// One block task, by wavefront `me` of the workgroup, in its own LDS region; the pair's codes are in the region of the
+// wavefront that swept it.
+template <bool STRICT>
+__device__ __forceinline__ void tf_block_task(const TraceArgs &A, const TFusedArgs &X, TfShared *sh, const uint32_t slot_id, const TfPair &P,
                                               const uint32_t kd, const uint32_t acc_lo, const uint32_t acc_hi,
-                                              const uint32_t lane, uint32_t *__restrict__ lds) {
-    // LDS of this wavefront (dwords): tile | cells [2 cap] | ops [cap][ops_words] | staged ops of one alignment, one per byte |
-    //                                 reference codes | read codes
-    uint32_t *tile = lds;
-    uint2 *cells = reinterpret_cast<uint2 *>(lds + X.tile_words);
-    uint32_t *opsb = lds + X.tile_words + 2u * X.cell_cap;
-    uint32_t *stage = opsb + X.cell_cap * X.ops_words;
-    uint8_t *stage_b = reinterpret_cast<uint8_t *>(stage);
-    const uint32_t *tile_w = tile;
+                                              const uint32_t me, const uint32_t lane, const TfRegion &R, const bool allow_push) {
+    TfSlot *slot = &sh->slot[slot_id];
     const int pmax = (int)slot->pmax;
     const uint32_t out_id = slot->out_id;
-    const uint32_t umat = (uint32_t)A.match, umis = (uint32_t)A.mismatch, ugap = (uint32_t)A.gap;
-    const uint32_t max_ops = 16u * X.ops_words;
     const uint32_t cap = X.cell_cap;
     uint32_t total = 0;
     // a block with more maximum cells than the list holds is taken `cap` cells at a time (each pass re-sweeps it)
     for (uint32_t base = 0;; base += cap) {
+        tf_wait_tile(A, sh, me);
         WAVE_SYNC();
-        const uint32_t found = tf_replay<STRICT>(P, lane, kd, tile, true, pmax, acc_lo, acc_hi, cells, cap, base);
+        const uint32_t found = tf_replay<STRICT>(P, lane, kd, R.tile, true, pmax, acc_lo, acc_hi, R.cells, cap, base);
         WAVE_SYNC();
         total = found;
         const uint32_t here = found > base ? (found - base < cap ? found - base : cap) : 0u;
-        uint32_t t_lo = P.B * kd;
-        uint32_t my_nops = 0, my_i = 0, my_j = 0;                          // lane a: header of alignment a of this pass
-        int my_begin = 0;
-        bool too_long = false;
-        // One alignment at a time, the whole wavefront on it: lane k looks at cell (i - k, j - k), the diagonal up-left of the
-        // current cell.  The leading lanes whose cell says "alignment" are one run of the path; a prefix sum of their score
-        // deltas finds where `while (score > 0)` (SmithWaterman.java:380) ends it.  The lane behind the run holds the gap move
-        // that follows.  One iteration per gap of the alignment instead of one per step.
-        for (uint32_t a = 0; a < here; ++a) {
-            const uint2 c0 = cells[a];
-            uint32_t i = tf_uni(c0.x), j = tf_uni(c0.y), score = (uint32_t)pmax, nops = 0;
-            int begin = 0;
-            for (uint32_t guard = 0;; ++guard) {
-                if (guard > 8192u) { too_long = true; break; }          // (a corrupted workspace must not hang the wavefront)
-                if (j - 1u < t_lo || j - 1u >= t_lo + TF_BW) {            // the block that holds column j - 1, right-aligned on it
-                    const uint32_t k2 = j > TF_BW ? (j - TF_BW + P.B - 1u) / P.B : 0u;
-                    WAVE_SYNC();
-                    (void)tf_replay<STRICT>(P, lane, k2, tile, false, pmax, 0u, 0u, cells, 0u, 0u);
-                    WAVE_SYNC();
-                    t_lo = P.B * k2;
+        // the alignments after the first go to the walk queue: their walkers read this tile while this wavefront walks the first
+        uint32_t pushed = 0;
+        if (here > 1u && allow_push) {
+            if (lane == 0) {
+                uint32_t at = tf_queue_lock(A, &sh->qw);
+                for (; pushed + 1u < here && at < TF_QCAP; ++pushed, ++at) {
+                    const uint2 c = R.cells[here - 1u - pushed];          // (the last `pushed` cells of the list)
+                    sh->qw.e[at] = make_uint4(slot_id | (me << 8), P.B * kd, c.x, c.y);
                 }
-                const bool valid = lane < i && lane < j && j - 1u - lane >= t_lo;
-                const uint32_t col = valid ? j - 1u - lane : t_lo, row = valid ? i - 1u - lane : 0u;
-                const uint32_t c = col - t_lo, la = c / TF_BR, kk = c - la * TF_BR, t = row + la;
-                const uint32_t dwv = tile_w[((t >> 4) * TF_BR + kk) * WAVE + la];
-                const uint32_t rc = P.ref_b[col], qc = P.read_b[row];
-                const uint32_t tag = (dwv >> (2u * (t & 15u))) & 3u;
-                const uint32_t op = STRICT ? 2u - tag : tag;             // SWMI_DIR_D 0, SWMI_DIR_I 1, SWMI_DIR_A 2
-                const bool isA = valid && op == SWMI_DIR_A;
-                const uint32_t cum = tf_scan_add(isA ? (rc == qc ? umat : umis) : 0u);   // SmithWaterman.java:388-406, H(pred) = H - delta
-                const uint64_t runm = ~BALLOT(isA);
-                const uint32_t r = runm ? (uint32_t)__builtin_ctzll(runm) : 64u;
-                const uint64_t inrun = r >= 64u ? ~0ull : ((1ull << r) - 1ull);
-                const uint64_t stopm = BALLOT((int)(score - cum) <= 0) & inrun;
-                const uint32_t r_eff = stopm ? (uint32_t)__builtin_ctzll(stopm) + 1u : r;
-                if (lane < r_eff && nops + lane < 4u * X.stage_words) stage_b[nops + lane] = (uint8_t)SWMI_DIR_A;
-                if (r_eff) {
-                    score -= (uint32_t)__builtin_amdgcn_readlane((int)cum, (int)(r_eff - 1u));
-                    nops += r_eff; i -= r_eff; j -= r_eff;
-                    begin = (int)(j + 1u);                               // SmithWaterman.java:383: the column of the last visited cell
-                }
-                if (stopm || (int)score <= 0 || i == 0u || j == 0u) break;       // `while (score > 0)` :380
-                if (r < 64u && __builtin_amdgcn_readlane((int)valid, (int)r)) {  // the gap move behind the run
-                    const uint32_t opg = (uint32_t)__builtin_amdgcn_readlane((int)op, (int)r);
-                    if (lane == 0 && nops < 4u * X.stage_words) stage_b[nops] = (uint8_t)opg;
-                    ++nops;
-                    begin = (int)j;
-                    score -= ugap;
-                    if (opg == SWMI_DIR_I) --i; else --j;
-                    if ((int)score <= 0 || i == 0u || j == 0u) break;
-                }
+                tf_lds_add(&slot->tasks_total, pushed);                   // (before anybody can take, let alone finish, one of them)
+                tf_lds_add(&sh->tile_users[me], pushed);
+                tf_queue_publish(&sh->qw, at);
             }
-            WAVE_SYNC();
-            // pack the staged ops (one per byte) into alignment a's slot, 16 per dword
-            if (nops <= max_ops) {
-                uint32_t *dst = opsb + a * X.ops_words;
-                for (uint32_t w = lane; w < (nops + 15u) / 16u; w += WAVE) {
-                    uint32_t v = 0;
-#pragma unroll
-                    for (uint32_t x = 0; x < 4u; ++x) {
-                        const uint32_t by = stage[4u * w + x];
-                        v |= ((by & 3u) | ((by >> 6) & 0xCu) | ((by >> 12) & 0x30u) | ((by >> 18) & 0xC0u)) << (8u * x);
-                    }
-                    const uint32_t rem = nops - 16u * w;
-                    if (rem < 16u) v &= (1u << (2u * rem)) - 1u;
-                    dst[w] = v;
-                }
-            } else too_long = true;
-            if (lane == a) { my_nops = nops; my_begin = begin; my_i = c0.x; my_j = c0.y; }
-            WAVE_SYNC();
+            pushed = tf_uni(pushed);
         }
-        // records of this pass: header + packed ops, contiguous for the whole wave
-        if (here) {
-            const bool mine = lane < here;
-            const uint32_t opw = (my_nops + 15u) / 16u;
-            const uint32_t words = mine ? SWMI_ALNREC_WORDS + opw : 0u;
-            const uint32_t incl = tf_scan_add(words);
-            const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-            unsigned long long off = 0;
-            if (lane == 0) off = atomicAdd(&A.hdr->used_words, (unsigned long long)tot);
-            off = ((unsigned long long)tf_uni((uint32_t)(off >> 32)) << 32) | tf_uni((uint32_t)off);
-            if (off + tot <= A.arena_cap_words && !too_long) {
-                if (mine) {
-                    uint32_t *dst = A.arena + off + (incl - words);
-                    const uint32_t *src = opsb + lane * X.ops_words;
-                    dst[0] = out_id; dst[1] = SWMI_RANK_BY_CELL; dst[2] = (uint32_t)my_begin;
-                    dst[3] = my_i; dst[4] = my_j; dst[5] = my_nops;
-                    for (uint32_t w = 0; w < opw; ++w) dst[SWMI_ALNREC_WORDS + w] = src[w];
-                }
-            } else if (lane == 0) {
-                atomicOr(&A.out[out_id].flags, SWMI_F_ARENA_OVF);
-                if (A.ovf_host) *A.ovf_host = 1u;
+        for (uint32_t a = 0; a + pushed < here; ++a) {
+            const uint2 c0 = R.cells[a];
+            const bool moved = tf_walk<STRICT>(A, X, sh, P, out_id, pmax, tf_uni(c0.x), tf_uni(c0.y), R.tile, P.B * kd, -1, me, lane, R);
+            if (moved && a + 1u + pushed < here) {                         // the walk left the block and re-swept another one into this tile
+                WAVE_SYNC();                                               // (no walk item can be reading it: the walk waited for them)
+                (void)tf_replay<STRICT>(P, lane, kd, R.tile, false, pmax, 0u, 0u, R.cells, 0u, 0u);
+                WAVE_SYNC();
             }
         }
         if (found <= base + cap) break;
     }
-    // the pair's count; whoever finishes the pair's last task writes its output
-    if (lane == 0) {
-        tf_lds_add(&slot->cells, total);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        const uint32_t done = tf_lds_add(&slot->tasks_done, 1u) + 1u;
-        if (done == tf_lds_load(&slot->tasks_total)) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            PairOut po;
-            po.score = pmax; po.n_cells = tf_lds_load(&slot->cells);
-            po.flags = SWMI_F_DONE | (atomicOr(&A.out[out_id].flags, 0u) & SWMI_F_ARENA_OVF);
-            A.out[out_id].score = po.score; A.out[out_id].n_cells = po.n_cells; atomicOr(&A.out[out_id].flags, SWMI_F_DONE);
-            if (A.out_host) A.out_host[out_id] = po;
-        }
-    }
+    tf_task_done(A, slot, total, lane);
 }
 
 template <bool STRICT>
@@ -417,14 +495,20 @@ __device__ __forceinline__ void tf_workgroup(const TraceArgs &A, const TFusedArg
     TfShared *sh = reinterpret_cast<TfShared *>(lds_all);
     uint32_t *regions = lds_all + (sizeof(TfShared) + 3u) / 4u;
     uint32_t *lds = regions + wave * X.lds_words;
-    const uint32_t region_codes = X.tile_words + 2u * X.cell_cap + X.cell_cap * X.ops_words + X.stage_words;   // reference codes | read codes
-    if (threadIdx.x < sizeof(TfShared) / 4u) lds_all[threadIdx.x] = 0u;
+    const uint32_t region_codes = X.tile_words + 2u * X.cell_cap + X.stage_words;   // reference codes | read codes
+    for (uint32_t w = threadIdx.x; w < sizeof(TfShared) / 4u; w += blockDim.x) lds_all[w] = 0u;
     __syncthreads();
 #define TF_MARK(v) do { if (X.debug_marks && A.ovf_host && lane == 0 && blockIdx.x == 0) *(volatile uint32_t *)&A.ovf_host[2u + wave] = (v); } while (0)
     TF_MARK(0x100u);
-    const uint32_t item = blockIdx.x * TF_WAVES + wave;
-    TfSlot *myslot = &sh->slot[wave];
+    if (wave >= TF_WAVES + X.n_helpers) return;                           // (no LDS region for this helper)
+    const uint32_t item = wave < TF_WAVES ? blockIdx.x * TF_WAVES + wave : 0xFFFFFFFFu;
+    TfSlot *myslot = &sh->slot[wave < TF_WAVES ? wave : 0u];
     const uint32_t g = (uint32_t)(-(int64_t)A.gap);
+    const TfRegion R = tf_region(X, lds);
+    const unsigned long long tk_start = A.dbg ? __builtin_amdgcn_s_memtime() : 0ull;       // diagnostics (SWMI_DEBUG_FILL)
+    unsigned long long tk_sweep = 0, tk_pro = 0, tk_task0 = 0, tk_idle = 0, n_taken = 0;
+    uint32_t dbg_id = 0xFFFFFFFFu;
+    bool counted = false;                                                  // this sweeper has announced that its tasks are in the queue
 
     // ---- A: this wavefront's own pair -------------------------------------------------------------------------------------
     if (item < X.n_items) {
@@ -439,6 +523,8 @@ __device__ __forceinline__ void tf_workgroup(const TraceArgs &A, const TFusedArg
         for (uint32_t w = lane; w < (n + 3u) / 4u; w += WAVE) refc[w] = refw[w];
         for (uint32_t w = lane; w < (m + 3u) / 4u; w += WAVE) readc[w] = readw[w];
         WAVE_SYNC();
+        dbg_id = pd.out_id;
+        if (A.dbg) tk_pro = __builtin_amdgcn_s_memtime() - tk_start;
         TfPair P;
         P.n = n; P.m = m;
         P.B = swmi_tf_cols_per_lane(n);
@@ -450,6 +536,7 @@ __device__ __forceinline__ void tf_workgroup(const TraceArgs &A, const TFusedArg
         P.g = g;
         int lane_max = 0;
         const int pmax = tf_sweep_dispatch(P, lane, lane_max);
+        if (A.dbg) tk_sweep = __builtin_amdgcn_s_memtime() - tk_start - tk_pro;
         TF_MARK(0x200u);
         if (pmax <= 0) {                                                   // every cell ties at 0: SmithWaterman.java:154,182-185
             PairOut po;
@@ -458,73 +545,52 @@ __device__ __forceinline__ void tf_workgroup(const TraceArgs &A, const TFusedArg
         } else {
             // candidate stripes, right to left, grouped into blocks: block tasks for the workgroup's queue
             uint64_t cand = BALLOT(lane_max == pmax && lane < P.L);
-            uint32_t acc_top = n, ntask = 0, kd_list[12], hi_list[12];
-            while (cand && ntask < 12u) {
-                const uint32_t ls = 63u - (uint32_t)__builtin_clzll(cand);
-                const uint32_t s_end = P.B * (ls + 1u);
-                const uint32_t kd = s_end > TF_BW ? (s_end - TF_BW + P.B - 1u) / P.B : 0u;
-                kd_list[ntask] = kd; hi_list[ntask] = s_end < acc_top ? s_end : acc_top;
-                ++ntask;
-                acc_top = P.B * kd;
-                cand &= kd ? ((1ull << kd) - 1ull) : 0ull;
-            }
+            // the checkpoints are read back by other lanes and wavefronts of this workgroup: stores done, loads through L2
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            const uint32_t own_ls = 63u - (uint32_t)__builtin_clzll(cand);
+            const uint32_t own_end = P.B * (own_ls + 1u);
+            const uint32_t own_kd = own_end > TF_BW ? (own_end - TF_BW + P.B - 1u) / P.B : 0u;
+            const uint32_t own_hi = own_end < n ? own_end : n;
             if (lane == 0) {
-                if (A.out) { PairOut po; po.score = pmax; po.flags = 0u; po.n_cells = 0; A.out[pd.out_id] = po; }
+                PairOut po; po.score = pmax; po.flags = 0u; po.n_cells = 0; A.out[pd.out_id] = po;
                 myslot->n = n; myslot->m = m; myslot->out_id = pd.out_id; myslot->pmax = (uint32_t)pmax;
                 const unsigned long long cka = (unsigned long long)(uintptr_t)P.ck;
                 myslot->ck_lo = (uint32_t)cka; myslot->ck_hi = (uint32_t)(cka >> 32);
-                myslot->tasks_total = ntask;
+                // the rightmost block is this wavefront's own next piece of work; the others go to the queue
+                uint32_t acc_top = own_hi, ntask = 1;
+                uint64_t rest = own_kd ? cand & ((1ull << own_kd) - 1ull) : 0ull;
+                acc_top = P.B * own_kd;
+                if (rest) {
+                    uint32_t at = tf_queue_lock(A, &sh->qb);
+                    while (rest && at < TF_QCAP) {
+                        const uint32_t ls = 63u - (uint32_t)__builtin_clzll(rest);
+                        const uint32_t s_end = P.B * (ls + 1u);
+                        const uint32_t kd = s_end > TF_BW ? (s_end - TF_BW + P.B - 1u) / P.B : 0u;
+                        sh->qb.e[at++] = make_uint4(wave, kd, P.B * kd, s_end < acc_top ? s_end : acc_top);
+                        ++ntask;
+                        acc_top = P.B * kd;
+                        rest &= kd ? ((1ull << kd) - 1ull) : 0ull;
+                    }
+                    myslot->tasks_total = ntask;
+                    tf_queue_publish(&sh->qb, at);
+                } else myslot->tasks_total = ntask;
             }
-            // the checkpoints are read back by other lanes and wavefronts of this workgroup: stores done, loads through L2
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            // append under a tiny spin lock (at most 4 contenders, once per pair); the count moves after the entries are written
-            if (lane == 0) {
-                for (uint32_t spins = 0; __hip_atomic_exchange(&sh->pad, 1u, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u; ++spins) {
-                    if (spins > (1u << 22)) { if (A.ovf_host) A.ovf_host[1] = 0xDEAD0001u; break; }      // (never seen: a wavefront must not hang)
-                    __builtin_amdgcn_s_sleep(1);
-                }
-                uint32_t at = tf_lds_load(&sh->q_n);
-                for (uint32_t x = 0; x < ntask && at < TF_QCAP; ++x, ++at) {
-                    sh->q[at] = (wave << 28) | kd_list[x];
-                    sh->q_hi[at] = hi_list[x];
-                    sh->q_lo[at] = P.B * kd_list[x];
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __hip_atomic_store(&sh->q_n, at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_store(&sh->pad, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
+            if (lane == 0) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); tf_lds_add(&sh->owners_done, 1u); }
+            counted = true;
+            const unsigned long long tt0 = A.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
+            tf_block_task<STRICT>(A, X, sh, wave, P, own_kd, P.B * own_kd, own_hi, wave, lane, R, X.n_helpers != 0u);
+            if (A.dbg) { tk_task0 = __builtin_amdgcn_s_memtime() - tt0; ++n_taken; }
         }
     }
     TF_MARK(0x300u);
-    if (lane == 0) {
+    if (lane == 0 && wave < TF_WAVES && !counted) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         tf_lds_add(&sh->owners_done, 1u);
     }
 
-    // ---- B + C: block tasks, any pair of the workgroup ----------------------------------------------------------------------
-    for (;;) {
-        uint32_t idx = 0;
-        if (lane == 0) idx = tf_lds_add(&sh->q_taken, 1u);
-        idx = tf_uni(idx);
-        TF_MARK(0x400u | idx);
-        bool have = false;
-        for (uint32_t spins = 0;; ++spins) {
-            if (spins > (1u << 22)) { if (lane == 0 && A.ovf_host) A.ovf_host[1] = 0xDEAD0002u; break; }    // (never seen: a wavefront must not hang)
-            const uint32_t qn = tf_lds_load(&sh->q_n);
-            if (idx < qn) { have = true; break; }
-            if (tf_lds_load(&sh->owners_done) >= TF_WAVES) {
-                if (idx < tf_lds_load(&sh->q_n)) { have = true; }
-                break;
-            }
-            __builtin_amdgcn_s_sleep(8);
-        }
-        if (!have) break;
-        TF_MARK(0x500u | idx);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        const uint32_t e = tf_uni(sh->q[idx]), acc_hi = tf_uni(sh->q_hi[idx]), acc_lo = tf_uni(sh->q_lo[idx]);
-        const uint32_t sw = e >> 28, kd = e & 0x0FFFFFFFu;
+    // ---- B + C: tasks, any pair of the workgroup ------------------------------------------------------------------------------
+    auto pair_of = [&](const uint32_t sw, TfPair &P) {
         TfSlot *slot = &sh->slot[sw];
-        TfPair P;
         P.n = tf_uni(slot->n); P.m = tf_uni(slot->m);
         P.B = swmi_tf_cols_per_lane(P.n);
         P.L = (P.n + P.B - 1u) / P.B;
@@ -534,15 +600,62 @@ __device__ __forceinline__ void tf_workgroup(const TraceArgs &A, const TFusedArg
         P.ck = reinterpret_cast<uint32_t *>((uintptr_t)(((unsigned long long)tf_uni(slot->ck_hi) << 32) | tf_uni(slot->ck_lo)));
         P.match = A.match; P.mismatch = A.mismatch;
         P.g = g;
-        tf_block_task<STRICT>(A, X, slot, P, kd, acc_lo, acc_hi, lane, lds);
-        TF_MARK(0x600u | idx);
+    };
+    // everybody: block tasks first, then walk items, until every pair of the workgroup is through.  A helper lists cells
+    // without handing any out (allow_push false): nobody ever reads a helper's tile, so a helper never waits.
+    for (uint32_t spins = 0;;) {
+        const unsigned long long ti0 = A.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
+        uint32_t idx = tf_queue_try_take(&sh->qb, lane);
+        if (idx != 0xFFFFFFFFu) {
+            TF_MARK(0x500u | idx);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const uint4 e = sh->qb.e[idx];
+            const uint32_t sw = tf_uni(e.x) & 0xFFu;
+            TfPair P;
+            pair_of(sw, P);
+            tf_block_task<STRICT>(A, X, sh, sw, P, tf_uni(e.y), tf_uni(e.z), tf_uni(e.w), wave, lane, R, wave < TF_WAVES && X.n_helpers != 0u);
+            ++n_taken;
+            spins = 0;
+            continue;
+        }
+        idx = X.n_helpers ? tf_queue_try_take(&sh->qw, lane) : 0xFFFFFFFFu;
+        if (idx != 0xFFFFFFFFu) {
+            TF_MARK(0x800u | idx);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const uint4 e = sh->qw.e[idx];
+            const uint32_t e0 = tf_uni(e.x), sw = e0 & 0xFFu, owner = (e0 >> 8) & 0xFFu;
+            TfSlot *slot = &sh->slot[sw];
+            TfPair P;
+            pair_of(sw, P);
+            const uint32_t *otile = regions + owner * X.lds_words;
+            (void)tf_walk<STRICT>(A, X, sh, P, tf_uni(slot->out_id), (int)tf_uni(slot->pmax), tf_uni(e.z), tf_uni(e.w), otile, tf_uni(e.y),
+                                  (int)owner, wave, lane, R);         // (its own tile too is given back before it may be overwritten)
+            tf_task_done(A, slot, 0u, lane);
+            spins = 0;
+            continue;
+        }
+        // nothing more can come once every sweeper has queued its tasks and every pair's tasks are done
+        if (tf_lds_load(&sh->owners_done) >= TF_WAVES) {
+            bool open = false;
+            for (uint32_t w = 0; w < TF_WAVES; ++w) open = open || tf_lds_load(&sh->slot[w].tasks_done) != tf_lds_load(&sh->slot[w].tasks_total);
+            if (!open) break;
+        }
+        if (++spins > (1u << 22)) { if (lane == 0 && A.ovf_host) A.ovf_host[1] = 0xDEAD0002u; break; }    // (never seen: a wavefront must not hang)
+        __builtin_amdgcn_s_sleep(8);
+        if (A.dbg) tk_idle += __builtin_amdgcn_s_memtime() - ti0;
     }
     TF_MARK(0x700u);
+    if (A.dbg && lane == 0 && dbg_id != 0xFFFFFFFFu) {   // {wave lifetime, sweep | prologue << 32, first block task << 16, block tasks taken | wait << 32}
+        A.dbg[4ull * dbg_id + 0] = __builtin_amdgcn_s_memtime() - tk_start;
+        A.dbg[4ull * dbg_id + 1] = (tk_sweep & 0xFFFFFFFFull) | (tk_pro << 32);
+        A.dbg[4ull * dbg_id + 2] = tk_task0 << 16;
+        A.dbg[4ull * dbg_id + 3] = n_taken | (tk_idle << 32);
+    }
 }
 
 }  // namespace
 
-extern "C" __global__ void __launch_bounds__(WAVE * TF_WAVES)
+extern "C" __global__ void __launch_bounds__(WAVE * (TF_WAVES + TF_HELPERS))
 sw_tfused_kernel(const TraceArgs A, const TFusedArgs X) {
     extern __shared__ uint32_t tf_lds[];
     const uint32_t wave = tf_uni(threadIdx.x >> 6), lane = threadIdx.x & 63u;
@@ -556,7 +669,7 @@ extern "C" hipError_t swmi_launch_tfused(const TraceArgs *a, const TFusedArgs *x
                                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); return true; }();
     (void)attr;
     const uint32_t groups = (x->n_items + TF_WAVES - 1) / TF_WAVES;
-    size_t lds = (size_t)TF_WAVES * x->lds_words * sizeof(uint32_t) + ((sizeof(TfShared) + 3u) / 4u) * 4u;
+    size_t lds = (size_t)(TF_WAVES + x->n_helpers) * x->lds_words * sizeof(uint32_t) + ((sizeof(TfShared) + 3u) / 4u) * 4u;
     // a launch that fits the chip once: an LDS request that keeps the dispatcher from stacking workgroups on some CUs while
     // others stay empty (swmi_kernels.hip, spread_lds)
     static const int spread = getenv("SWMI_LDS_SPREAD") ? atoi(getenv("SWMI_LDS_SPREAD")) : 1;
@@ -564,6 +677,6 @@ extern "C" hipError_t swmi_launch_tfused(const TraceArgs *a, const TFusedArgs *x
         const size_t even = ((size_t)(160u * 1024u) / ((groups + 255u) / 256u)) & ~(size_t)1023;
         if (even > lds) lds = even;
     }
-    hipLaunchKernelGGL(sw_tfused_kernel, dim3(groups), dim3(WAVE * TF_WAVES), lds, st, *a, *x);
+    hipLaunchKernelGGL(sw_tfused_kernel, dim3(groups), dim3(WAVE * (TF_WAVES + TF_HELPERS)), lds, st, *a, *x);
     return hipGetLastError();
 }
