@@ -225,6 +225,10 @@ struct swmi_batch {
     // raw record streams of the last run (one per launch chunk), indexed lazily on the first alignment access
     struct RawChunk { size_t at, words; size_t lo; std::vector<uint32_t> wpos; };   // wpos: re-run chunks only
     std::vector<uint32_t> raw;
+    // a run of ONE launch with results in pinned memory leaves its record stream where the kernels wrote it (the pinned block
+    // is the batch's own and lives until the next run): copied into `raw` only when something needs it there
+    const uint32_t *raw_ext = nullptr;
+    size_t raw_ext_words = 0;
     std::vector<RawChunk> raw_chunks;
     bool indexed = false;
     std::vector<HostAln> alns;              // grouped by pair, ordered as OptAlignments returns them
@@ -522,6 +526,7 @@ struct RunState {
     double enqueue_us = 0, wait_us = 0, copyout_us = 0;
     bool one_wave_sweep = false;            // the strip pipeline gave up once in this run: long reads are swept by one wavefront
     bool tb_split = false;                  // mode 1: detect per window + walk per alignment instead of one workgroup per pair
+    bool defer_copy = false;                // this launch is the whole run: its record stream may stay in the pinned block
 };
 
 // layout of the device result block: [ArenaHdr | PairOut x np | arena words ...]
@@ -1126,12 +1131,21 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
                                   hipMemcpyDeviceToHost));
             ctx->arena_copy_wpp = arena_used * 5 / (4 * np) + 2;
         }
-        // the record stream is appended to the caller's vector (the batch's raw stream): one copy out of the pinned block
-        arena_copy.insert(arena_copy.end(), (const uint32_t *)(h + a_off), (const uint32_t *)(h + a_off) + arena_used);
+        // the record stream is appended to the caller's vector (the batch's raw stream): one copy out of the pinned block --
+        // or, for the only launch of a run, left in the pinned block (settle_raw)
+        if (rs.defer_copy && zc && &arena_copy == &b->raw && arena_copy.empty()) { b->raw_ext = (const uint32_t *)(h + a_off); b->raw_ext_words = arena_used; }
+        else arena_copy.insert(arena_copy.end(), (const uint32_t *)(h + a_off), (const uint32_t *)(h + a_off) + arena_used);
         for (auto &o : outs) o.flags &= ~SWMI_F_ARENA_OVF;
         rs.copyout_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - c2).count();
         return SWMI_OK;
     }
+}
+
+// the record stream left in the pinned block moves into the batch's own vector
+static void settle_raw(swmi_batch *b) {
+    if (!b->raw_ext) return;
+    b->raw.assign(b->raw_ext, b->raw_ext + b->raw_ext_words);
+    b->raw_ext = nullptr; b->raw_ext_words = 0;
 }
 
 // records of one chunk -> per-pair lists (tmp, keyed by position in `work`)
@@ -1163,6 +1177,7 @@ static int parse_records(const uint32_t *arena, uint64_t used, size_t lo, const 
 // Turns the raw record streams of the last run into per-pair alignment lists (first use of an alignment accessor).
 static int ensure_indexed(swmi_batch *b) {
     if (b->indexed) return SWMI_OK;
+    settle_raw(b);
     const std::vector<Work> &work = b->work;
     std::vector<ParsedRec> recs;
     b->ops.clear();
@@ -1249,6 +1264,7 @@ extern "C" int swmi_batch_run(swmi_ctx *ctx, swmi_batch *b, const swmi_params *p
     b->pairs.assign(n_pairs, PairRes{});
     b->alns.clear(); b->ops.clear(); b->str_at.clear();
     b->raw.clear(); b->raw_chunks.clear(); b->indexed = false;
+    b->raw_ext = nullptr; b->raw_ext_words = 0;
     if (b->views_built || b->ref_view_ready.size() != n_refs) {     // (a run nobody read MapRef views of leaves them as they are)
         b->ref_view_ready.assign(n_refs, 0);
         b->ref_sites.assign(n_refs, {});
@@ -1358,7 +1374,9 @@ extern "C" int swmi_batch_run(swmi_ctx *ctx, swmi_batch *b, const swmi_params *p
         dir_bytes += words * 4;
         uint64_t used = 0;
         const size_t raw_at = b->raw.size();
+        rs.defer_copy = lo == 0 && hi == work.size();
         int rc = run_chunk(rs, work, lo, hi, nullptr, outs, b->raw, used);
+        rs.defer_copy = false;
         if (rc) return rc;
         for (size_t k = 0; k < hi - lo; k++) {
             PairRes &pr = b->pairs[work[lo + k].pair];
@@ -1374,6 +1392,7 @@ extern "C" int swmi_batch_run(swmi_ctx *ctx, swmi_batch *b, const swmi_params *p
     const auto h2 = now();
     // pairs with more tied cells than cell_cap: run them again on the GPU with exact-size lists
     if (!ovf.empty()) {
+        settle_raw(b);                                   // (the re-run writes the pinned block again)
         std::vector<Work> w2;
         std::vector<uint64_t> exact;
         for (size_t pos : ovf) { w2.push_back(work[pos]); exact.push_back(b->pairs[work[pos].pair].n_cells); }
@@ -1798,6 +1817,7 @@ static int stream_process(swmi_stream *s, swmi_stream::Slot &sl, StreamChunk *c)
     r->work = std::move(b->work); b->work.clear(); b->work_mode = -1;
     r->work_mode = (int)r->eff_mode;
     r->pairs = std::move(b->pairs);
+    settle_raw(b);
     r->raw = std::move(b->raw);
     r->raw_chunks = std::move(b->raw_chunks);
     r->indexed = false;
