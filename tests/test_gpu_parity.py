@@ -422,6 +422,31 @@ def test_resident_pairs_engineerdata_shapes(ctx):
     b.free()
 
 
+def test_transposed_fused_blocks_ties_and_long_paths(ctx):
+    """What sw_tfused_kernel (option "tfused") has that the small cases do not reach: tied maxima in DISTANT blocks of one
+    reference (block tasks), more tied maxima in one block than its cell list holds (passes), several alignments per block
+    (walk items read another wavefront's tile), paths longer than a block (the walk re-sweeps the block on the left), both tie
+    modes, references at the edges of the columns-per-lane classes.  Every score and alignment against the oracle; the other
+    context variants run the same batch through their own kernels."""
+    rng = random.Random(77)
+    rnd = lambda n: "".join(rng.choice("ACGT") for _ in range(n))     # noqa: E731
+    read = rnd(150)
+    planted = rnd(300) + read + rnd(700) + read + rnd(600) + read[:149] + rnd(40)          # the read three times, far apart
+    near = rnd(500) + read + "ACGT" + read + rnd(300)                                      # ... and twice within one block
+    refs = [planted, near, (REF * 30)[:2000], "ACGTTGCA" * 250, rnd(2047), rnd(2049), rnd(2560), rnd(127), rnd(129), read, read[::-1] * 8]
+    reads = [read, REF[10:60], rnd(150), "ACGTTGCA" * 12]
+    check_batch(ctx, refs, reads)
+    check_batch(ctx, refs[:5], reads[:2] + reads[3:], tie=1)
+    # long reads and a cheap gap: paths of several hundred columns leave their 320-column block
+    long_reads = [rnd(256), (planted[100:330] + "TTGACCA")[:237]]
+    check_batch(ctx, [planted, rnd(1500)], long_reads, scores=(5, -3, -1))
+    check_batch(ctx, [planted], long_reads[:1], scores=(7, -8, -1), tie=1)
+    b = ctx.upload(refs, reads).run()
+    if b.pipeline_mode() == 1 and ctx.test_tfused == 1:
+        assert b.timing().tfused_pairs >= len(refs) * len(reads) - 4            # (all but the pairs with an empty... none here: every pair qualifies)
+    b.free()
+
+
 def test_config4_full_size_pair(ctx):
     """configs[4] at full size: one 10 kbp x 10 kbp pair (40 strips of 256 read rows, 10^8 cells) against the oracle --
     score, every tied maximum, every alignment string (full size had only been checked run to run)."""
