@@ -228,7 +228,7 @@ struct swmi_batch {
     // a run of ONE launch with results in pinned memory leaves its record stream where the kernels wrote it (the pinned block
     // is the batch's own and lives until the next run): copied into `raw` only when something needs it there
     const uint32_t *raw_ext = nullptr;
-    size_t raw_ext_words = 0;
+    uint64_t raw_ext_records = 0, raw_ext_cap = 0;
     std::vector<RawChunk> raw_chunks;
     bool indexed = false;
     std::vector<HostAln> alns;              // grouped by pair, ordered as OptAlignments returns them
@@ -896,10 +896,10 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
         xt.debug_marks = tf_marks ? 1u : 0u;
         xt.lds_words = (xt.tile_words + 2u * xt.cell_cap + xt.stage_words + xt.ref_words + xt.read_words + 3u) & ~3u;
         {   // helper wavefronts while their LDS regions fit beside the four sweepers' (160 KB per workgroup)
-            static const int tf_helpers = getenv("SWMI_TF_HELPERS") ? atoi(getenv("SWMI_TF_HELPERS")) : 2;
+            static const int tf_helpers = getenv("SWMI_TF_HELPERS") ? atoi(getenv("SWMI_TF_HELPERS")) : 2;      // (diagnostics: 0 .. SWMI_TF_HELPERS)
             const uint64_t region = 4ull * xt.lds_words, budget = 156ull * 1024;      // (160 KB less the workgroup's queues)
             const uint64_t left = budget > 4 * region ? budget - 4 * region : 0;
-            xt.n_helpers = (uint32_t)std::min<uint64_t>((uint64_t)std::max(0, std::min(tf_helpers, 2)), region ? left / region : 0);
+            xt.n_helpers = (uint32_t)std::min<uint64_t>((uint64_t)std::max(0, std::min(tf_helpers, (int)SWMI_TF_HELPERS)), region ? left / region : 0);
         }
         const bool zc = ctx->zero_copy != 0;
         if (zc) {
@@ -939,6 +939,7 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
             rs.launches++;
         }
         if (n_tf) HIP_TRY(swmi_launch_tfused(&ta, &xt, ctx->stream));             // (sweep AND traceback of its pairs: timed with the sweep)
+        if (whole_only && n_tf) rs.launches++;
         if (ctx->profiling) HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));     // end of the sweep = start of the traceback
         if (n_res) HIP_TRY(swmi_launch_resident(&ta, &xa, ctx->stream));          // (timed with the traceback)
         if (attempt == 0) b->timing.resident_pairs += (uint32_t)n_res;
@@ -1026,6 +1027,19 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
                 }
                 fprintf(stderr, "[swmi tfused dbg] ticks per sweeper wavefront: lifetime mean=%.0f max=%llu = prologue %.0f + sweep %.0f + first block task %.0f (%.2f block tasks per wavefront) + waiting for tasks %.0f + rest (more tasks, walk items) %.0f\n",
                         t0 / np, mx, t2 / np, t1 / np, t3 / np, t5 / np, t4 / np, (t0 - t1 - t2 - t3 - t4) / np);
+                {   // the distribution of the wavefront lifetimes and the slowest ones
+                    std::vector<size_t> idx(np);
+                    for (size_t k = 0; k < np; k++) idx[k] = k;
+                    std::sort(idx.begin(), idx.end(), [&](size_t x, size_t y) { return d[4 * x] < d[4 * y]; });
+                    auto at = [&](double q) { return d[4 * idx[std::min<size_t>(np - 1, (size_t)(q * np))]]; };
+                    fprintf(stderr, "[swmi tfused dbg]   lifetime p10=%llu p50=%llu p90=%llu p99=%llu max=%llu\n", at(0.10), at(0.50), at(0.90), at(0.99), d[4 * idx[np - 1]]);
+                    for (size_t t = 0; t < std::min<size_t>(np, 6); t++) {
+                        const size_t k = idx[np - 1 - t];
+                        fprintf(stderr, "[swmi tfused dbg]   slow wavefront (pair %zu): lifetime %llu, sweep %llu, first block task %llu, block tasks taken %llu, waiting %llu, alignments of its pair %llu\n",
+                                k, d[4 * k], d[4 * k + 1] & 0xFFFFFFFFull, d[4 * k + 2] >> 16, d[4 * k + 3] & 0xFFFFFFFFull, d[4 * k + 3] >> 32,
+                                (unsigned long long)((const PairOut *)((const uint8_t *)b->h_result.p + result_out_off()))[k].n_cells);
+                    }
+                }
             }
             double a0 = 0, a1 = 0, a2 = 0, a3 = 0; unsigned long long mx = 0;
             double a4 = 0;
@@ -1118,6 +1132,15 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
             for (auto &o : outs)
                 if (!(o.flags & (SWMI_F_DEGENERATE | SWMI_F_CELL_OVF))) expect += o.n_cells;
             const uint32_t *aw = (const uint32_t *)(h + a_off);
+            if (rs.defer_copy && &arena_copy == &b->raw && arena_copy.empty()) {
+                // the only launch of the run: the stream stays in the pinned block, and how long it is -- a walk from record to
+                // record, 6 us per 1000 pairs -- is found out when something needs it in the batch's vector (settle_raw)
+                b->raw_ext = aw; b->raw_ext_records = expect; b->raw_ext_cap = arena_cap;
+                arena_used = 0;
+                for (auto &o : outs) o.flags &= ~SWMI_F_ARENA_OVF;
+                rs.copyout_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - c2).count();
+                return SWMI_OK;
+            }
             for (uint64_t k = 0; k < expect; k++) {
                 if (at + SWMI_ALNREC_WORDS > arena_cap) return fail(SWMI_ERR_HIP, "record stream overruns the arena");
                 at += SWMI_ALNREC_WORDS + ((uint64_t)aw[at + 5] + 15) / 16;
@@ -1133,8 +1156,7 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
         }
         // the record stream is appended to the caller's vector (the batch's raw stream): one copy out of the pinned block --
         // or, for the only launch of a run, left in the pinned block (settle_raw)
-        if (rs.defer_copy && zc && &arena_copy == &b->raw && arena_copy.empty()) { b->raw_ext = (const uint32_t *)(h + a_off); b->raw_ext_words = arena_used; }
-        else arena_copy.insert(arena_copy.end(), (const uint32_t *)(h + a_off), (const uint32_t *)(h + a_off) + arena_used);
+        arena_copy.insert(arena_copy.end(), (const uint32_t *)(h + a_off), (const uint32_t *)(h + a_off) + arena_used);
         for (auto &o : outs) o.flags &= ~SWMI_F_ARENA_OVF;
         rs.copyout_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - c2).count();
         return SWMI_OK;
@@ -1142,10 +1164,19 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
 }
 
 // the record stream left in the pinned block moves into the batch's own vector
-static void settle_raw(swmi_batch *b) {
-    if (!b->raw_ext) return;
-    b->raw.assign(b->raw_ext, b->raw_ext + b->raw_ext_words);
-    b->raw_ext = nullptr; b->raw_ext_words = 0;
+static int settle_raw(swmi_batch *b) {
+    if (!b->raw_ext) return SWMI_OK;
+    const uint32_t *aw = b->raw_ext;
+    b->raw_ext = nullptr;
+    uint64_t at = 0;
+    for (uint64_t k = 0; k < b->raw_ext_records; k++) {
+        if (at + SWMI_ALNREC_WORDS > b->raw_ext_cap) return fail(SWMI_ERR_HIP, "record stream overruns the arena");
+        at += SWMI_ALNREC_WORDS + ((uint64_t)aw[at + 5] + 15) / 16;
+    }
+    if (at > b->raw_ext_cap) return fail(SWMI_ERR_HIP, "record stream overruns the arena");
+    b->raw.assign(aw, aw + at);
+    if (b->raw_chunks.size() == 1) b->raw_chunks[0].words = (size_t)at;
+    return SWMI_OK;
 }
 
 // records of one chunk -> per-pair lists (tmp, keyed by position in `work`)
@@ -1177,7 +1208,7 @@ static int parse_records(const uint32_t *arena, uint64_t used, size_t lo, const 
 // Turns the raw record streams of the last run into per-pair alignment lists (first use of an alignment accessor).
 static int ensure_indexed(swmi_batch *b) {
     if (b->indexed) return SWMI_OK;
-    settle_raw(b);
+    { int rc0 = settle_raw(b); if (rc0) return rc0; }
     const std::vector<Work> &work = b->work;
     std::vector<ParsedRec> recs;
     b->ops.clear();
@@ -1264,7 +1295,7 @@ extern "C" int swmi_batch_run(swmi_ctx *ctx, swmi_batch *b, const swmi_params *p
     b->pairs.assign(n_pairs, PairRes{});
     b->alns.clear(); b->ops.clear(); b->str_at.clear();
     b->raw.clear(); b->raw_chunks.clear(); b->indexed = false;
-    b->raw_ext = nullptr; b->raw_ext_words = 0;
+    b->raw_ext = nullptr;
     if (b->views_built || b->ref_view_ready.size() != n_refs) {     // (a run nobody read MapRef views of leaves them as they are)
         b->ref_view_ready.assign(n_refs, 0);
         b->ref_sites.assign(n_refs, {});
@@ -1392,7 +1423,7 @@ extern "C" int swmi_batch_run(swmi_ctx *ctx, swmi_batch *b, const swmi_params *p
     const auto h2 = now();
     // pairs with more tied cells than cell_cap: run them again on the GPU with exact-size lists
     if (!ovf.empty()) {
-        settle_raw(b);                                   // (the re-run writes the pinned block again)
+        { int rc0 = settle_raw(b); if (rc0) return rc0; }       // (the re-run writes the pinned block again)
         std::vector<Work> w2;
         std::vector<uint64_t> exact;
         for (size_t pos : ovf) { w2.push_back(work[pos]); exact.push_back(b->pairs[work[pos].pair].n_cells); }
@@ -1817,7 +1848,7 @@ static int stream_process(swmi_stream *s, swmi_stream::Slot &sl, StreamChunk *c)
     r->work = std::move(b->work); b->work.clear(); b->work_mode = -1;
     r->work_mode = (int)r->eff_mode;
     r->pairs = std::move(b->pairs);
-    settle_raw(b);
+    (void)settle_raw(b);
     r->raw = std::move(b->raw);
     r->raw_chunks = std::move(b->raw_chunks);
     r->indexed = false;

@@ -188,8 +188,12 @@ struct TFusedArgs {
     uint32_t        debug_marks; // diagnostics: workgroup 0 leaves progress marks in the host-mapped result header
     uint32_t        n_helpers;   // wavefronts per workgroup (0..2) beyond the four that sweep: they only take block tasks
 };
+#define SWMI_TF_HELPERS 2u          // wavefronts per workgroup beyond the four sweepers, at most
 #define SWMI_TF_BMAX   40u          // columns per lane of the transposed sweep: references up to 64 * 40 = 2560 bases
-#define SWMI_TF_BR     5u           // columns per lane of a re-swept block (320 columns: a 150 bp read's path fits with room)
+#ifndef SWMI_TF_BR
+#define SWMI_TF_BR     4u           // columns per lane of a re-swept block: 256 columns (5: 320 columns, fewer walks leave the block, but every
+                                    // re-sweep costs 14 % more -- measured 0.166 against 0.149 ms at the headline)
+#endif
 #define SWMI_TF_MAX_M  256u         // reads up to 256 bases (LDS tile of a block: (m + 63) / 16 KB)
 // columns per lane for a reference of n bases (even: the kernel is instantiated for 2, 4, ..., SWMI_TF_BMAX)
 SWMI_HD static inline uint32_t swmi_tf_cols_per_lane(uint32_t n) {

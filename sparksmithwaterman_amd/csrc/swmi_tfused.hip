@@ -37,9 +37,10 @@
 
 #define WAVE 64
 #define TF_WAVES 4                       // wavefronts of a workgroup that sweep a pair each
-#define TF_HELPERS 2                     // ... and wavefronts that only take block tasks
+#define TF_HELPERS SWMI_TF_HELPERS       // ... and wavefronts that only take tasks (at most)
 #define TF_BR SWMI_TF_BR                 // columns per lane of a re-swept block
 #define TF_BW (64u * TF_BR)              // ... and its width
+#define TF_ACC (TF_BR >= 5u ? 2u : 1u)   // candidate stripes a block takes cells from, counted from its right edge
 #define BALLOT(pred) __builtin_amdgcn_ballot_w64(pred)
 #define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 
@@ -119,9 +120,14 @@ __device__ __forceinline__ int tf_sweep(const TfPair &P, const uint32_t lane, in
                 w = tf_subsat(x, P.g);
                 hp[k] = w;
             }
+            int Mn = M;
 #pragma unroll
-            for (int k = 0; k + 1 < B; k += 2) M = tf_max3(M, H[k], H[k + 1]);
-            if (B & 1) M = M > H[B - 1] ? M : H[B - 1];
+            for (int k = 0; k + 1 < B; k += 2) Mn = tf_max3(Mn, H[k], H[k + 1]);
+            if (B & 1) Mn = Mn > H[B - 1] ? Mn : H[B - 1];
+            // rows past the read's end copy the row above diagonally (zero one-hot): they must not carry the maximum into
+            // the stripes to the right, which would then be re-swept for nothing.  Only the last L - 1 steps have such rows.
+            if (t0 + r < P.m) M = Mn;
+            else              M = (t0 + r - lane < P.m) ? Mn : M;
             ckrow[lane] = (uint32_t)H[B - 1];
         }
     }
@@ -547,39 +553,57 @@ __device__ __forceinline__ void tf_workgroup(const TraceArgs &A, const TFusedArg
             uint64_t cand = BALLOT(lane_max == pmax && lane < P.L);
             // the checkpoints are read back by other lanes and wavefronts of this workgroup: stores done, loads through L2
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            // A block is right-aligned on a candidate stripe and takes the cells of that stripe and the one before it: cells
+            // further left would have little of the block to their left, and their walks would leave it at once -- they get a
+            // block of their own (which another wavefront can take).
             const uint32_t own_ls = 63u - (uint32_t)__builtin_clzll(cand);
             const uint32_t own_end = P.B * (own_ls + 1u);
             const uint32_t own_kd = own_end > TF_BW ? (own_end - TF_BW + P.B - 1u) / P.B : 0u;
             const uint32_t own_hi = own_end < n ? own_end : n;
+            const uint32_t own_first = own_ls + 1u >= own_kd + TF_ACC ? own_ls + 1u - TF_ACC : own_kd;      // first stripe whose cells this block takes
+            uint64_t left_rest = 0;
+            uint32_t left_top = 0;
             if (lane == 0) {
                 PairOut po; po.score = pmax; po.flags = 0u; po.n_cells = 0; A.out[pd.out_id] = po;
                 myslot->n = n; myslot->m = m; myslot->out_id = pd.out_id; myslot->pmax = (uint32_t)pmax;
                 const unsigned long long cka = (unsigned long long)(uintptr_t)P.ck;
                 myslot->ck_lo = (uint32_t)cka; myslot->ck_hi = (uint32_t)(cka >> 32);
                 // the rightmost block is this wavefront's own next piece of work; the others go to the queue
-                uint32_t acc_top = own_hi, ntask = 1;
-                uint64_t rest = own_kd ? cand & ((1ull << own_kd) - 1ull) : 0ull;
-                acc_top = P.B * own_kd;
+                uint32_t acc_top = P.B * own_first, ntask = 1;
+                uint64_t rest = own_first ? cand & ((1ull << own_first) - 1ull) : 0ull;
                 if (rest) {
                     uint32_t at = tf_queue_lock(A, &sh->qb);
-                    while (rest && at < TF_QCAP) {
+                    while (rest) {
                         const uint32_t ls = 63u - (uint32_t)__builtin_clzll(rest);
                         const uint32_t s_end = P.B * (ls + 1u);
                         const uint32_t kd = s_end > TF_BW ? (s_end - TF_BW + P.B - 1u) / P.B : 0u;
-                        sh->qb.e[at++] = make_uint4(wave, kd, P.B * kd, s_end < acc_top ? s_end : acc_top);
+                        const uint32_t first = ls + 1u >= kd + TF_ACC ? ls + 1u - TF_ACC : kd;
+                        if (at < TF_QCAP) sh->qb.e[at++] = make_uint4(wave, kd, P.B * first, s_end < acc_top ? s_end : acc_top);
+                        else if (!left_rest) { left_rest = rest; left_top = acc_top; }     // (queue full: this wavefront does the rest itself)
                         ++ntask;
-                        acc_top = P.B * kd;
-                        rest &= kd ? ((1ull << kd) - 1ull) : 0ull;
+                        acc_top = P.B * first;
+                        rest &= first ? ((1ull << first) - 1ull) : 0ull;
                     }
                     myslot->tasks_total = ntask;
                     tf_queue_publish(&sh->qb, at);
                 } else myslot->tasks_total = ntask;
             }
+            left_rest = ((uint64_t)tf_uni((uint32_t)(left_rest >> 32)) << 32) | tf_uni((uint32_t)left_rest);
+            left_top = tf_uni(left_top);
             if (lane == 0) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); tf_lds_add(&sh->owners_done, 1u); }
             counted = true;
             const unsigned long long tt0 = A.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
-            tf_block_task<STRICT>(A, X, sh, wave, P, own_kd, P.B * own_kd, own_hi, wave, lane, R, X.n_helpers != 0u);
+            tf_block_task<STRICT>(A, X, sh, wave, P, own_kd, P.B * own_first, own_hi, wave, lane, R, X.n_helpers != 0u);
             if (A.dbg) { tk_task0 = __builtin_amdgcn_s_memtime() - tt0; ++n_taken; }
+            while (left_rest) {                                            // blocks that did not fit the queue
+                const uint32_t ls = 63u - (uint32_t)__builtin_clzll(left_rest);
+                const uint32_t s_end = P.B * (ls + 1u);
+                const uint32_t kd = s_end > TF_BW ? (s_end - TF_BW + P.B - 1u) / P.B : 0u;
+                const uint32_t first = ls + 1u >= kd + TF_ACC ? ls + 1u - TF_ACC : kd;
+                tf_block_task<STRICT>(A, X, sh, wave, P, kd, P.B * first, s_end < left_top ? s_end : left_top, wave, lane, R, X.n_helpers != 0u);
+                left_top = P.B * first;
+                left_rest &= first ? ((1ull << first) - 1ull) : 0ull;
+            }
         }
     }
     TF_MARK(0x300u);
