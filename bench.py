@@ -169,6 +169,9 @@ def main():
     batch.run(params)
     mode = batch.pipeline_mode()             # the pipeline the library chose for this batch (or the one forced above)
     kernel_name = {0: "sw_fill_kernel", 1: "sw_sweep_winmax_kernel", 2: "sw_fill_score_kernel"}[mode]
+    tfused = batch.timing().tfused_pairs == len(refs) * len(reads)      # option --tfused 1: sweep AND traceback in one launch
+    if tfused:
+        kernel_name = "sw_tfused_kernel (sweep + traceback of every pair in one launch)"
 
     gids = np.arange(id0, id0 + len(refs), dtype=np.int64)
 
@@ -264,7 +267,7 @@ def main():
         if os.path.exists(tf):
             try:
                 prof = json.load(open(tf))
-                traffic = prof.get("fill_kernel_hbm_bytes_per_launch")
+                traffic = None if tfused else prof.get("fill_kernel_hbm_bytes_per_launch")
             except Exception:
                 prof, traffic = {}, None
         # supplementary: the bound that actually holds for this integer recurrence is instruction issue (DESIGN.md
@@ -272,7 +275,7 @@ def main():
         issue = None
         try:
             ipp = prof.get("sweep_insts_per_pair_headline")
-            if ipp and (m, args.ref_len, len(refs), len(reads)) == (150, 2000, 1000, 1) and mode == 1 and fill_avg_s > 0:
+            if ipp and (m, args.ref_len, len(refs), len(reads)) == (150, 2000, 1000, 1) and mode == 1 and fill_avg_s > 0 and not tfused:
                 insts = (ipp["valu"] + ipp["salu"]) * len(refs) * len(reads)
                 nominal = 1024 * 2.4e9 / 2.0         # SIMDs x max clock / 2 cycles per wave64 VALU (the guide's nominal rate)
                 lone = 1024 * 2.4e9 / 4.0            # ... / 4 cycles: what ONE wave per SIMD can issue (guide, 'one wave alone: 4')
@@ -293,7 +296,7 @@ def main():
                              "alignments": int(n_aln_all), "chars": int(n_chars),
                              "gcups": round(cells_rank / (ms_mat * 1e-3) / 1e9, 3)},
             "config": {"workload": "configs[1]: 1 read x %d bp vs %d refs x %d bp per GPU, scores 5/-3/-4, mode %d: %s"
-                                   % (m, len(refs), args.ref_len, mode, WORKLOAD_OF_MODE[mode]),
+                                   % (m, len(refs), args.ref_len, mode, "transposed sweep (column checkpoints) + block re-sweeps + walks + result records, ONE kernel (option tfused)" if tfused else WORKLOAD_OF_MODE[mode]),
                        "pairs_per_gpu": len(refs) * len(reads), "cells_per_step_per_gpu": cells_rank,
                        "parallelism": "references sharded over %d rank(s); max/top-K reduce %s"
                                       % (world, ("over gloo (one-GPU rehearsal)" if one_gpu else "over RCCL") if world > 1 else "local")},

@@ -372,8 +372,9 @@ __device__ __forceinline__ bool tf_walk(const TraceArgs &A, const TFusedArgs &X,
         const bool valid = lane < i && lane < j && j - 1u - lane >= t_lo;
         const uint32_t col = valid ? j - 1u - lane : t_lo, row = valid ? i - 1u - lane : 0u;
         const uint32_t c = col - t_lo, la = c / TF_BR, kk = c - la * TF_BR, t = row + la;
-        const uint32_t dwv = tile_w[((t >> 4) * TF_BR + kk) * WAVE + la];
-        const uint32_t rc = P.ref_b[col], qc = P.read_b[row];
+        uint32_t dwv = tile_w[((t >> 4) * TF_BR + kk) * WAVE + la];
+        uint32_t rc = P.ref_b[col], qc = P.read_b[row];
+        asm volatile("" : "+v"(dwv), "+v"(rc), "+v"(qc));              // (the three LDS reads in flight together: one wait, not two)
         const uint32_t tag = (dwv >> (2u * (t & 15u))) & 3u;
         const uint32_t op = STRICT ? 2u - tag : tag;                     // SWMI_DIR_D 0, SWMI_DIR_I 1, SWMI_DIR_A 2
         const bool isA = valid && op == SWMI_DIR_A;
