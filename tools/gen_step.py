@@ -29,6 +29,12 @@ pads with s_nop where an instruction order cannot avoid it):
 import os
 import sys
 
+# Rows 1 .. R-1 accumulate NW + s IN PLACE with the 4-byte VOP2 form v_dot8c_i32_i4 (dst += dot): the accumulator is the
+# previous step's H of the row above, which nothing reads again (W comes from hp, the next step overwrites the whole set, and
+# the neighbour lane only ever reads row R-1).  Same instruction count, 4 bytes less per cell: with several wavefronts per SIMD
+# the 8-byte encodings issue at half the rate of the 4-byte ones (tools/ubench_occ.hip), so big batches gain; one wavefront per
+# SIMD is indifferent.  SWMI_GEN_DOT8C=0 generates the three-address form.
+DOT8C = os.environ.get("SWMI_GEN_DOT8C", "1") != "0"
 DOT_WAIT = 3
 DPP_WAIT = 2
 SGPR_WAIT = 2     # gfx940/gfx950: a VALU writes an SGPR, a VALU reads it
@@ -58,8 +64,12 @@ def stream(R, odd, feed_byte, tail=False):
     if tail:
         ins.append(Ins("v_cmp_lt_u32_e32 vcc, %[c], %[n]", wr=["vcc"], rd=["c", "n"]))       # this lane's column is inside the reference
     ins.append(Ins(f"v_dot8_i32_i4 %[s0], %[q0], %[{RB}], 0", wr=["s0"], dot=["s0"], rd=["q0", RB]))
+    an = lambda k: f"{H}{k-1}" if DOT8C else f"a{k}"             # where a_k = NW + s of row k lives
     for k in range(1, R):
-        ins.append(Ins(f"v_dot8_i32_i4 %[a{k}], %[q{k}], %[{RB}], {hin(k-1)}", wr=[f"a{k}"], dot=[f"a{k}"], rd=[f"q{k}", RB, f"{H}{k-1}"]))
+        if DOT8C:
+            ins.append(Ins(f"v_dot8c_i32_i4_e32 {hin(k-1)}, %[q{k}], %[{RB}]", wr=[an(k)], dot=[an(k)], rd=[f"q{k}", RB, f"{H}{k-1}"]))
+        else:
+            ins.append(Ins(f"v_dot8_i32_i4 %[a{k}], %[q{k}], %[{RB}], {hin(k-1)}", wr=[f"a{k}"], dot=[f"a{k}"], rd=[f"q{k}", RB, f"{H}{k-1}"]))
     ins.append(Ins(f"v_lshlrev_b32_sdwa %[{RBN}], %[{WF}], %[one] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_{feed_byte} src1_sel:DWORD",
                    wr=[RBN], rd=[WF, "one"]))
     ins.append(Ins(f"v_max_i32_dpp %[x], {hp(R-1)}, {hp(0)} {dpp}", wr=["x"], rd=["p0"], dpp_rd=[f"p{R-1}"]))
@@ -68,7 +78,7 @@ def stream(R, odd, feed_byte, tail=False):
     ins.append(Ins(f"v_max_i32_e32 {hout(0)}, %[a0], %[x]", wr=[f"{G}0"], rd=["a0", "x"]))
     ins.append(Ins(f"v_sub_u32_e64 {hp(0)}, {hout(0)}, %[gm] clamp", wr=["p0"], rd=[f"{G}0"]))
     for k in range(1, R):
-        ins.append(Ins(f"v_max3_i32 {hout(k)}, %[a{k}], {hp(k-1)}, {hp(k)}", wr=[f"{G}{k}"], rd=[f"a{k}", f"p{k-1}", f"p{k}"]))
+        ins.append(Ins(f"v_max3_i32 {hout(k)}, %[{an(k)}], {hp(k-1)}, {hp(k)}", wr=[f"{G}{k}"], rd=[an(k), f"p{k-1}", f"p{k}"]))
         ins.append(Ins(f"v_sub_u32_e64 {hp(k)}, {hout(k)}, %[gm] clamp", wr=[f"p{k}"], rd=[f"{G}{k}"]))
     # window maximum: even steps consume 2*floor(R/2) of their values, odd steps the leftover row of the even step + their own
     vals = [hout(k) for k in range(R)]
@@ -172,7 +182,10 @@ def dir_stream(R, odd, feed_byte, strict):
     ins = []
     ins.append(Ins(f"v_dot8_i32_i4 %[s0], %[q0], %[{RB}], 0", wr=["s0"], dot=["s0"], rd=["q0", RB]))
     for k in range(1, R):
-        ins.append(Ins(f"v_dot8_i32_i4 %[a{k}], %[q{k}], %[{RB}], {hin(k-1)}", wr=[f"a{k}"], dot=[f"a{k}"], rd=[f"q{k}", RB, f"{H}{k-1}"]))
+        if DOT8C:
+            ins.append(Ins(f"v_dot8c_i32_i4_e32 {hin(k-1)}, %[q{k}], %[{RB}]", wr=[f"{H}{k-1}"], dot=[f"{H}{k-1}"], rd=[f"q{k}", RB, f"{H}{k-1}"]))
+        else:
+            ins.append(Ins(f"v_dot8_i32_i4 %[a{k}], %[q{k}], %[{RB}], {hin(k-1)}", wr=[f"a{k}"], dot=[f"a{k}"], rd=[f"q{k}", RB, f"{H}{k-1}"]))
     ins.append(Ins(f"v_lshlrev_b32_sdwa %[{RBN}], %[{WF}], %[one] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_{feed_byte} src1_sel:DWORD",
                    wr=[RBN], rd=[WF, "one"]))
     ins.append(Ins(f"v_mov_b32_dpp %[x], {hp(R-1)} {dpp}", wr=["x"], dpp_rd=[f"p{R-1}"]))                      # hp(N) of row 0
@@ -184,7 +197,7 @@ def dir_stream(R, odd, feed_byte, strict):
     for k in range(R):
         up = "%[x]" if k == 0 else hp(k - 1)
         upn = "x" if k == 0 else f"p{k-1}"
-        ak = "a0" if k == 0 else f"a{k}"
+        ak = "a0" if k == 0 else (f"{H}{k-1}" if DOT8C else f"a{k}")
         sI, sA = (("sI0", "sA0") if k % 2 == 0 else ("sI1", "sA1"))
         ins.append(Ins(f"{cmpI} %[{sI}], {up}, {hp(k)}", rd=[upn, f"p{k}"], sg_wr=[sI]))
         if strict:
