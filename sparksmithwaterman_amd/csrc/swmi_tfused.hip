@@ -1,35 +1,36 @@
-// swmi_tfused.hip -- gfx950 kernel: ONE WAVEFRONT DOES ONE PAIR FROM START TO FINISH, in the TRANSPOSED layout.
+// swmi_tfused.hip -- gfx950 kernel: sweep AND traceback of a pair in ONE launch, in the TRANSPOSED layout (option "tfused").
 //
 // Same results as the sweep + traceback kernels of swmi_kernels.hip (ScoreMatrix.call src/sw/SmithWaterman.java:129-190,
 // GetCellScore.call :217-252 / DistributedSW.java:305-330, GetAlignment.call :354-436) for the usual pair: both sequences of
 // fast symbols, int4 scores, gap < 0, a read of at most 256 bases, a reference of at most 64 * SWMI_TF_BMAX bases.
+// Measurements and the decision to leave it opt-in: DESIGN.md 4.4.
 //
 // Why transposed.  The sweep of swmi_kernels.hip puts the READ's rows on the lanes (R = 3 rows per lane at 150 bp) and
 // streams the reference through: n + 63 steps of 3 R cell instructions + ~8 of per-step overhead (neighbour exchange, symbol
 // feed, window maximum, checkpoints).  At 150 x 2000 that is 2050 x 17 = 34.8 k instructions per pair, half of them overhead,
-// and the chip is issue- (in fact power-) bound: tools/ubench_occ.hip, 0.41 G wave-instructions/s per SIMD with one wave,
-// 0.55 with eight.  Here the lanes own the REFERENCE's columns, B = ceil(n / 64) consecutive columns each (B = 32 at 2 kbp),
-// and the read's rows stream through: m + 63 steps of 3.5 B + ~8 instructions = 214 x 120 = 25.7 k.  The per-step overhead is
-// paid 214 times instead of 2050 times; what the pipeline fill costs more (64 of 214 steps instead of 50 of 2050) is less.
+// and one wavefront per SIMD issues one instruction per ~5 cycles whatever it is (tools/ubench_occ.hip): what counts is the
+// count.  Here the lanes own the REFERENCE's columns, B = ceil(n / 64) consecutive columns each (B = 32 at 2 kbp), and the
+// read's rows stream through: m + 62 steps of 3.5 B + ~20 instructions = 212 x 133 = 28.2 k.  The per-step overhead is paid
+// 212 times instead of 2050 times; what the pipeline fill costs more (62 of 212 steps instead of 50 of 2050) is less.
 //
 //   A  sweep: lane l, step t, row i = t - l, columns B*l .. B*l+B-1.  Per cell v_dot8_i32_i4 (one-hot read symbol . the
 //      column's 8 x int4 score profile + the diagonal), v_max3_i32, v_sub_u32 clamp (hp = max(H + gap, 0)), and half a
 //      v_max3 for the lane's running maximum.  N comes from the lane's own registers, W from the cell before in the same
 //      step, NW/W of a lane's first column from lane l-1 by DPP.  The read symbol moves down the lanes by one DPP shift per
 //      step.  Every step each lane stores the H of its LAST column: 256 coalesced bytes -- column checkpoints
-//      ck[t][l] = H(t - l, B*(l+1) - 1), (m + 63) x 256 B per pair (55 KB at 150 bp, against 83 KB of lane-state checkpoints
-//      before).  Lanes that have not started compute zeros from zeros, lanes past the read's end and padding columns see a
-//      zero one-hot / zero profile and cannot exceed the true maximum: no masking anywhere.
-//   B  the lanes whose maximum equals the pair's name the candidate stripes.  A BLOCK of 64 * TF_BR (320) columns whose left edge is a
-//      checkpointed column is re-swept with TF_BR columns per lane, the left column fed from the checkpoints, rows streaming from
-//      a zero top row: scores are kept x 4 with the move in the two low bits (alignment 2 > insertion 1 > deletion 0, or the
-//      reverse for the strict mode), so that ONE v_max3 yields score and direction with the reference's tie order; the two
-//      bits are shifted into a direction word per column (v_alignbit) and every 16 steps a lane stores its words to LDS.
-//      Cells equal to the maximum are listed on the way.
-//   C  all alignments of the pair are walked at once, one LANE each, through the block in LDS (score tracked like
-//      SmithWaterman.java:380-409); lanes that leave the block on the left wait, the block that holds the rightmost of them is
-//      re-swept, and so on.  Records are appended to the arena exactly like sw_resident_pairs_kernel does.
-// More tied cells than lanes reserved: SWMI_F_CELL_OVF, no records, the host re-runs the pair through the ordinary path.
+//      ck[t][l] = H(t - l, B*(l+1) - 1), (m + 62) x 256 B per pair (54 KB at 150 bp, against 83 KB of lane-state checkpoints).
+//      Lanes that have not started compute zeros from zeros, rows past the read's end and padding columns see a zero one-hot /
+//      zero profile and cannot exceed the true maximum: nothing is masked but the lanes' maxima in the last L - 1 steps.
+//   B  the lanes whose maximum equals the pair's name the candidate stripes.  A BLOCK of 64 * TF_BR (256) columns, right-aligned
+//      on a candidate stripe, left edge on a checkpointed column, is re-swept with TF_BR columns per lane, the left column fed
+//      from the checkpoints, rows streaming from a zero top row: scores are kept x 4 with the move in the two low bits (alignment
+//      2 > insertion 1 > deletion 0, or the reverse for the strict mode), so that ONE v_max3 yields score and direction with the
+//      reference's tie order; the two bits are shifted into a direction word per column (v_alignbit) and every 16 steps a lane
+//      stores its words to LDS.  Cells of the stripe equal to the maximum are listed on the way.
+//   C  an alignment is walked by a whole wavefront, a run of "alignment" moves per iteration (tf_walk); a walk that leaves its
+//      block re-sweeps the block on its left.  Its record goes straight to the arena (format of swmi_device.h: AlnRec).
+// The four sweeping wavefronts of a workgroup and two helpers share B and C through two queues in LDS: block tasks and walk
+// items (below).  Nothing overflows: a block with more tied cells than its list holds is taken in passes.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
