@@ -92,6 +92,41 @@ def test_two_contexts_on_two_threads():
 
 
 @pytest.mark.gpu
+def test_repeated_runs_header_ring_and_deferred_record_stream():
+    """Host-side bookkeeping of repeated runs (swmi_api.cpp): a launch of whole-pair kernels only takes its arena header from a
+    ring of 1024 zeroed slots (1100 runs wrap it); the record stream of a single-launch run stays in the pinned block until an
+    alignment is asked for, so a second run must not disturb what the first one handed out, and results read after any number
+    of runs are the last run's."""
+    from oracle import sw_oracle as orc
+    ref = "CCTGGGTCCTGCCTCGCATCTGACCAGGGCAGGTGGCCTCCTCATCACACTGCTGCCTCTGCTGTTGGCCCTGCTCATGA"      # EngineerData.java:23
+    refs = [ref * 5] * 300 + [ref[::-1] * 5] * 20
+    reads = [ref[7:87], "ACTGACTGACTGACTGACTG"]
+    want = {(r, q): orc.opt_alignments((r, q)) for r in set(refs) for q in reads}
+    for resident, tfused in ((1, 0), (0, 1), (0, 0)):
+        ctx = sw.Context(0)
+        ctx.set_option("resident", resident)
+        ctx.set_option("tfused", tfused)
+        b = ctx.upload(refs, reads)
+        p1 = sw.make_params((5, -3, -4))
+        p2 = sw.make_params((1, -1, -1))
+        n_runs = 1100 if resident else 40
+        for k in range(n_runs):
+            b.run(p1)
+            if k % 275 == 3:
+                for pair in (0, 1, 2 * 300, 2 * 319 + 1):
+                    es, ea = want[(refs[pair // 2], reads[pair % 2])]
+                    assert b.score(pair) == es and b.alignments(pair) == ea, (resident, tfused, k, pair)
+        first = b.alignments(5)                  # (indexes the stream of the last run)
+        b.run(p2)                                # another run with other scores: its stream replaces the pinned block's content
+        es2, ea2 = orc.opt_alignments((refs[5 // 2], reads[5 % 2]), (1, -1, -1))
+        assert b.score(5) == es2 and b.alignments(5) == ea2
+        b.run(p1)
+        assert b.alignments(5) == first == want[(refs[2], reads[1])][1]
+        b.free()
+        ctx.close()
+
+
+@pytest.mark.gpu
 def test_strip_pipeline_give_up_falls_back_to_one_wave_sweep():
     """Long reads are swept one wavefront per strip, each strip waiting for the one above it.  With the items dispatched
     consumer-first and a spin budget of one poll the consumers give up; the runtime must then re-run the chunk with the
