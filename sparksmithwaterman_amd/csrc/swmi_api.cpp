@@ -30,8 +30,8 @@
 #include "swmi_device.h"
 #include "swmi_io_internal.h"
 
-extern "C" hipError_t swmi_launch_fill(const FillArgs *a, hipStream_t st);
-extern "C" hipError_t swmi_launch_traceback(const TraceArgs *a, hipStream_t st);
+extern "C" hipError_t swmi_launch_fill(const FillArgs *a, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop);
+extern "C" hipError_t swmi_launch_traceback(const TraceArgs *a, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop);
 extern "C" hipError_t swmi_launch_traceback_split(const TraceArgs *a, uint32_t n_windows, hipStream_t st);
 extern "C" hipError_t swmi_launch_resident(const TraceArgs *a, const ResidentArgs *x, hipStream_t st);
 extern "C" hipError_t swmi_launch_tfused(const TraceArgs *a, const TFusedArgs *x, hipStream_t st);
@@ -125,6 +125,8 @@ struct swmi_ctx {
     uint32_t auto_ties_x100 = 300;          // automatic mode: mode 0 when a sampled pair has this many tied maxima (x 1/100) on average
     uint32_t col_chunks = 0;                // test knob: force this many column chunks per pair (0 = automatic)
     int tb_split = -1;                      // mode-1 traceback grain: -1 automatic, 0 one workgroup per pair, 1 one wavefront per window / alignment
+    bool ext_events = false;                // SWMI_EXT_EVENTS=1: the plain two-kernel run is timed by the dispatches' own start/stop times (pure kernel
+                                            // durations, as rocprofv3 shows them) -- measured 8-12 us per run DEARER than three hipEventRecord, so off
     int tfused = -1;                        // transposed sweep + traceback by one wavefront per pair (swmi_tfused.hip): -1 automatic, 0 never, 1 whenever a pair qualifies
     int resident = -1;                      // small pairs handled by one wavefront with the direction field in LDS: -1 automatic, 0 never, 1 whenever it fits
     bool cell_cap_set = false;              // cell_cap given by the caller (otherwise small launches get longer lists)
@@ -303,6 +305,7 @@ extern "C" int swmi_create(int device, swmi_ctx **out) {
         if (e != hipSuccess) { ev = nullptr; ctx_release(c); return fail(SWMI_ERR_HIP, "hipEventCreate: %s", hipGetErrorString(e)); }
     }
     { int r = c->h_err.reserve(64); if (r) { ctx_release(c); return r; } }
+    { static const char *ee = getenv("SWMI_EXT_EVENTS"); if (ee) c->ext_events = atoi(ee) != 0; }
     *(volatile uint32_t *)c->h_err.p = 0u;
     { int r = c->d_lut.reserve(256); if (r) { ctx_release(c); return r; } }
     e = hipMemcpy(c->d_lut.p, code_table(), 256, hipMemcpyHostToDevice);
@@ -932,15 +935,21 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
             }
             ta.hdr = (ArenaHdr *)(ctx->d_hdr_ring.as<uint8_t>() + (size_t)ctx->hdr_next++ * 64);
         }
-        if (ctx->profiling) HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
+        // diagnostics (SWMI_EXT_EVENTS=1): the plain case -- one sweep kernel, one traceback kernel -- timed by the kernels' own
+        // dispatches instead of by events around them (the three events cost 3.5 us per run, tests/manual/prof_events_ab.py;
+        // hipExtLaunchKernelGGL's start/stop events cost more: profiles/r02/ab_ext_events.txt)
+        const bool split_now = rs.tb_split && !cells_exact && b->eff_mode == 1 && n_windows < 0xFFFFFFFFull;
+        const bool ext_timing = ctx->profiling && attempt == 0 && !whole_only && !n_res && !n_tf && !split_now && b->eff_mode == 1 &&
+                                !fa.n_strip_items && !fa.n_col_items && ctx->ext_events;
+        if (ctx->profiling && !ext_timing) HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
         if (attempt == 0 && !whole_only) {       // the workspace survives an arena-overflow retry
             if (fa.n_strip_items) HIP_TRY(hipMemsetAsync(fa.progress, 0, (size_t)fa.n_strip_items * sizeof(uint32_t), ctx->stream));
-            HIP_TRY(swmi_launch_fill(&fa, ctx->stream));
+            HIP_TRY(swmi_launch_fill(&fa, ctx->stream, ext_timing ? ctx->ev[0] : nullptr, ext_timing ? ctx->ev[1] : nullptr));
             rs.launches++;
         }
         if (n_tf) HIP_TRY(swmi_launch_tfused(&ta, &xt, ctx->stream));             // (sweep AND traceback of its pairs: timed with the sweep)
         if (whole_only && n_tf) rs.launches++;
-        if (ctx->profiling) HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));     // end of the sweep = start of the traceback
+        if (ctx->profiling && !ext_timing) HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));     // end of the sweep = start of the traceback
         if (n_res) HIP_TRY(swmi_launch_resident(&ta, &xa, ctx->stream));          // (timed with the traceback)
         if (attempt == 0) b->timing.resident_pairs += (uint32_t)n_res;
         if (attempt == 0) b->timing.tfused_pairs += (uint32_t)n_tf;
@@ -956,9 +965,9 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
             HIP_TRY(hipMemsetAsync(ta.q_count, 0, 4, ctx->stream));
             HIP_TRY(swmi_launch_traceback_split(&ta, (uint32_t)n_windows, ctx->stream));
         } else if (n_res + n_tf < np) {
-            HIP_TRY(swmi_launch_traceback(&ta, ctx->stream));
+            HIP_TRY(swmi_launch_traceback(&ta, ctx->stream, ext_timing ? ctx->ev[2] : nullptr, ext_timing ? ctx->ev[3] : nullptr));
         }
-        if (ctx->profiling) HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
+        if (ctx->profiling && !ext_timing) HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
 
         // without zero-copy: one D2H of header + pair outputs + as much of the arena as the previous run used
         // (plus slack); the rare remainder is fetched after the header has been read
@@ -1013,7 +1022,7 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
         if (ctx->profiling) {
             float ms = 0;
             if (attempt == 0 || whole_only) { HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1])); rs.fill_ms += ms; }
-            HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[3])); rs.tb_ms += ms;
+            HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[ext_timing ? 2 : 1], ctx->ev[3])); rs.tb_ms += ms;
             if (!zc) { HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4])); rs.d2h_ms += ms; }
         }
         if (ta.dbg) {

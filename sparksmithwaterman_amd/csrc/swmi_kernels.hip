@@ -26,6 +26,7 @@
 //   (H(pred) = H - delta, so `while (score > 0)` of SmithWaterman.java:380 needs no score matrix),
 //   stages the 2-bit ops in LDS and appends one variable-length record per alignment to an arena.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include "swmi_device.h"
@@ -2079,7 +2080,9 @@ static void allow_big_lds(K kernel) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
-extern "C" hipError_t swmi_launch_fill(const FillArgs *a, hipStream_t st) {
+// ev_start / ev_stop (both or none): the launch is ONE kernel and the events take its start and stop times from the dispatch
+// itself (hipExtLaunchKernelGGL) -- no marker packets between the kernels of a run, which hipEventRecord would put there
+extern "C" hipError_t swmi_launch_fill(const FillArgs *a, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
     if (a->n_pairs == 0) return hipSuccess;
     static const bool attrs = [] {
         allow_big_lds(sw_fill_kernel); allow_big_lds(sw_fill_score_kernel); allow_big_lds(sw_sweep_winmax_kernel);
@@ -2091,6 +2094,10 @@ extern "C" hipError_t swmi_launch_fill(const FillArgs *a, hipStream_t st) {
     const size_t lds = spread_lds(grid.x);
     if (a->mode == 0)      hipLaunchKernelGGL(sw_fill_kernel, grid, block, lds, st, *a);
     else if (a->mode == 1) {
+        if (ev_start && ev_stop && !(a->skip_multi && a->n_strip_items) && !a->n_col_items) {
+            hipExtLaunchKernelGGL(sw_sweep_winmax_kernel, grid, block, (uint32_t)lds, st, ev_start, ev_stop, 0u, *a);
+            return hipGetLastError();
+        }
         hipLaunchKernelGGL(sw_sweep_winmax_kernel, grid, block, a->n_col_items || a->n_strip_items ? 0 : lds, st, *a);
         if (a->skip_multi && a->n_strip_items) {
             const uint32_t g = (a->n_strip_items + FILL_WAVES - 1) / FILL_WAVES;
@@ -2121,7 +2128,7 @@ extern "C" hipError_t swmi_launch_traceback_split(const TraceArgs *a, uint32_t n
     return hipGetLastError();
 }
 
-extern "C" hipError_t swmi_launch_traceback(const TraceArgs *a, hipStream_t st) {
+extern "C" hipError_t swmi_launch_traceback(const TraceArgs *a, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
     if (a->n_pairs == 0) return hipSuccess;
     const size_t tile = (size_t)(a->mode == 0 ? SWMI_TB_BLOCKS : SWMI_CK_BLOCKS) * SWMI_RMAX * WAVE;
     const size_t per_wave = (size_t)a->lds_words + a->lds_read_words + SWMI_TB_REFWIN_WORDS + tile;
@@ -2137,7 +2144,10 @@ extern "C" hipError_t swmi_launch_traceback(const TraceArgs *a, hipStream_t st) 
         const size_t n_walkers = n_waves < SWMI_TB_SLOTS ? n_waves : SWMI_TB_SLOTS;
         const size_t words = 32 + (size_t)n_waves * SWMI_CK_BLOCKS * SWMI_RMAX * WAVE +
                              n_walkers * ((size_t)a->lds_words + a->lds_read_words + SWMI_TB_REFWIN_WORDS);
-        hipLaunchKernelGGL(sw_traceback_winmax_kernel, dim3(a->n_pairs), dim3(WAVE * n_waves), words * sizeof(uint32_t), st, *a);
+        if (ev_start && ev_stop)
+            hipExtLaunchKernelGGL(sw_traceback_winmax_kernel, dim3(a->n_pairs), dim3(WAVE * n_waves), (uint32_t)(words * sizeof(uint32_t)), st, ev_start, ev_stop, 0u, *a);
+        else
+            hipLaunchKernelGGL(sw_traceback_winmax_kernel, dim3(a->n_pairs), dim3(WAVE * n_waves), words * sizeof(uint32_t), st, *a);
     } else {
         const dim3 grid((a->n_pairs + FILL_WAVES - 1) / FILL_WAVES, SWMI_TB_SLOTS);
         if (a->mode == 0) hipLaunchKernelGGL(sw_traceback_kernel, grid, block, per_wave * FILL_WAVES * sizeof(uint32_t), st, *a);
