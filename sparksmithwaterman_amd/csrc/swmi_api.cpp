@@ -891,7 +891,6 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
         xt.n_items = (uint32_t)n_tf;
         xt.cell_cap = 16;
         xt.tile_words = ((tf_max_m + 63u + 15u) / 16u) * 64u * SWMI_TF_BR;
-        xt.ops_words = (tf_max_path + 15u) / 16u + 1u;
         xt.ref_words = (tf_max_n + 3u) / 4u + 1u;
         xt.read_words = (tf_max_m + 3u) / 4u + 1u;
         xt.stage_words = (tf_max_path + 3u) / 4u + 1u;

@@ -178,10 +178,10 @@ struct ResidentArgs {
 struct TFusedArgs {
     const uint32_t *items;       // indices into pairs[]
     uint32_t        n_items;
-    uint32_t        lds_words;   // LDS dwords per wavefront: tile | cells | ops | reference codes | read codes
+    uint32_t        lds_words;   // LDS dwords per wavefront: tile | cells | staged ops | reference codes | read codes
     uint32_t        tile_words;  // direction tile of one block: ceil((m_max + 63) / 16) * 64 * SWMI_TF_BR
-    uint32_t        cell_cap;    // alignments one pair may have here (one lane each; more: SWMI_F_CELL_OVF, re-run by the ordinary path)
-    uint32_t        ops_words;   // dwords of packed ops a lane can stage (the longest possible path of the launch)
+    uint32_t        cell_cap;    // maximum cells a block lists per pass (a block with more is re-swept once per `cell_cap` cells)
+    uint32_t        pad0;
     uint32_t        ref_words;   // LDS dwords for the longest reference's codes
     uint32_t        read_words;  // ... and the longest read's
     uint32_t        stage_words; // LDS dwords for the ops of ONE alignment staged one per byte (the longest possible path)

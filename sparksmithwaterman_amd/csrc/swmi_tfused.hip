@@ -252,10 +252,11 @@ __device__ __forceinline__ int tf_sweep_dispatch(const TfPair &P, uint32_t lane,
 }
 
 // ---- workgroup-shared state (LDS) ------------------------------------------------------------------------------------
-// The first 4 wavefronts of a workgroup sweep 4 pairs, one each.  What follows the sweep comes in TASKS any wavefront of the
-// workgroup may take -- the sweepers once their own pair is through, and up to two helper wavefronts that do nothing else:
-//   block task: one candidate block of one pair -- re-sweep it into the taker's tile, list its maximum cells, walk the first
-//               alignment, hand the others out as walk items;
+// The first 4 wavefronts of a workgroup sweep 4 pairs, one each, and go on with the rightmost candidate block of their pair.
+// Everything else comes in TASKS any wavefront of the workgroup may take -- the sweepers once their own block is through, and up
+// to two helper wavefronts that do nothing else:
+//   block task: one more candidate block of a pair -- re-sweep it into the taker's tile, list its maximum cells, walk the first
+//               alignment; a sweeper hands the other alignments out as walk items, a helper walks them itself;
 //   walk item:  one alignment, walked through the tile of the wavefront that listed it (LDS is shared), into a record.
 // With one wavefront per SIMD the launch lasts as long as its slowest pair: a pair with tied maxima in several blocks, or
 // three alignments to walk, must not be the work of one wavefront.
@@ -273,12 +274,13 @@ struct TfQueue {
 struct TfShared {
     uint32_t owners_done, pad[3];
     uint32_t tile_users[8];          // walk items still reading this wavefront's tile
-    TfQueue qb;                      // block tasks {slot, first stripe, accepted columns lo, hi}: taken by the sweepers
-    TfQueue qw;                      // walk items {slot | tile owner << 8, t_lo, i, j}: taken by the helpers, and by sweepers with no block task left
+    TfQueue qb;                      // block tasks {slot, first stripe of the block, accepted columns lo, hi}
+    TfQueue qw;                      // walk items {slot | tile owner << 8, first column of the tile, i, j}
     TfSlot slot[TF_WAVES];
 };
-// Who waits for whom: a wavefront waits only for the walk items that read ITS tile (before it overwrites the tile).  Helpers
-// never list cells, so nobody reads their tiles and they never wait: every walk item is taken and finished in the end.
+// Who waits for whom: a wavefront waits only for the walk items that read ITS tile, before it overwrites the tile.  Helpers hand
+// no walk items out, so nobody reads their tiles and they never wait: every walk item is taken and finished in the end, and
+// every wait of a sweeper ends.  Every wait is bounded all the same (a give-up raises a host-visible error code).
 
 
 __device__ __forceinline__ uint32_t tf_lds_add(uint32_t *p, uint32_t v) {
@@ -288,7 +290,7 @@ __device__ __forceinline__ uint32_t tf_lds_load(const uint32_t *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// lane 0 appends to a queue of the workgroup: lock, write entries at tf_queue_at() + k, publish the new count
+// lane 0 appends to a queue of the workgroup: lock (returns the count), write the entries behind it, publish the new count
 __device__ __forceinline__ uint32_t tf_queue_lock(const TraceArgs &A, TfQueue *q) {
     for (uint32_t spins = 0; __hip_atomic_exchange(&q->lock, 1u, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u; ++spins) {
         if (spins > (1u << 22)) { if (A.ovf_host) A.ovf_host[1] = 0xDEAD0001u; break; }          // (never seen: a wavefront must not hang)
