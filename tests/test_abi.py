@@ -58,3 +58,16 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp")):
                 txt = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "sw_oracle" not in txt and "import oracle" not in txt and "from oracle" not in txt, f
+
+
+def test_generated_instruction_streams_are_what_the_generators_emit():
+    """swmi_step_gen.inc / swmi_cells_gen.inc are committed: a change to tools/gen_step.py or tools/gen_cells.py (or a hand edit
+    of the .inc) that is not regenerated would ship a kernel the scripts' hazard checks never saw."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("SWMI_GEN_DOT8C", None)
+    for script in ("gen_step.py", "gen_cells.py"):
+        p = subprocess.run([sys.executable, os.path.join(root, "tools", script), "--check"], capture_output=True, text=True, env=env)
+        assert p.returncode == 0, (script, p.stdout[-300:], p.stderr[-300:])

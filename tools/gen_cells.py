@@ -171,8 +171,13 @@ def main():
                 parts.append("")
             parts.append(emit(R, acgt, False, False))     # scores do not depend on the tie order
             parts.append("")
+    text = "\n".join(parts)
+    if "--check" in sys.argv:                       # tests/test_abi.py: the committed file is what this script generates
+        same = os.path.exists(path) and open(path).read() == text
+        print("up to date" if same else "STALE: re-run tools/gen_cells.py", path)
+        return 0 if same else 1
     with open(path, "w") as f:
-        f.write("\n".join(parts))
+        f.write(text)
     print("wrote", path)
 
 

@@ -312,8 +312,13 @@ def main():
             parts.append(text)
             parts.append("")
             print(f"R={R} {'strict' if strict else 'serial'} with direction bits: {(nv + nn) / 4:.2f} instructions per step, {nn} s_nop per 4 steps")
+    text = "\n".join(parts)
+    if "--check" in sys.argv:                       # tests/test_abi.py: the committed file is what this script generates
+        same = os.path.exists(path) and open(path).read() == text
+        print("up to date" if same else "STALE: re-run tools/gen_step.py", path)
+        return 0 if same else 1
     with open(path, "w") as f:
-        f.write("\n".join(parts))
+        f.write(text)
     print("wrote", path)
 
 
