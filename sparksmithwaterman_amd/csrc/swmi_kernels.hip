@@ -32,6 +32,9 @@
 #include "swmi_device.h"
 
 #define WAVE 64
+#ifndef SWMI_HELPER_SLEEP
+#define SWMI_HELPER_SLEEP 8          // x 64 cycles between two polls of an idle helper wavefront of the traceback (measured: profiles/r02/ab_helper_sleep.txt)
+#endif
 #define BALLOT(pred) __builtin_amdgcn_ballot_w64(pred)
 // LDS hand-offs between lanes of ONE wavefront: DS operations of a wave execute in order, so a compiler-level
 // fence is all that is needed (a workgroup barrier would deadlock the fused kernel's 4 independent waves)
@@ -1450,7 +1453,7 @@ __device__ __forceinline__ void coop_helper(const TraceArgs &A, const PairDesc p
     for (;;) {
         uint32_t seq;
         while ((seq = __hip_atomic_load(const_cast<uint32_t *>(&shared[7u + 4u * team]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == last)
-            __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_s_sleep(SWMI_HELPER_SLEEP);
         if (seq == 0xFFFFFFFFu) break;
         last = seq;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
