@@ -51,6 +51,7 @@ def parse_args():
     ap.add_argument("--col-chunks", type=int, default=None, help="column chunks per pair (include/swmi.h): 0 automatic, 1 never, N force")
     ap.add_argument("--tfused", type=int, default=None, help="transposed fused kernel (include/swmi.h): -1 automatic, 0 never, 1 every pair that qualifies")
     ap.add_argument("--mode", type=int, default=None, help="kernel pipeline (include/swmi.h): 1 default, 2 event-tracked maxima, 0 HBM direction field")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="any swmi_set_option knob, e.g. device_strings=0 (A/B runs)")
     return ap.parse_args()
 
 
@@ -164,6 +165,9 @@ def main():
         ctx.set_option("tfused", args.tfused)
     if args.d2h_copy:
         ctx.set_option("zero_copy", 0)
+    for kv in args.opt:
+        name, _, value = kv.partition("=")
+        ctx.set_option(name, int(value))
     batch = ctx.upload(refs, reads)          # H2D happens here, outside the timed region
     params = sw.make_params()
     batch.run(params)

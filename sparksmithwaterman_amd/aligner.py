@@ -1,5 +1,6 @@
 """Context / Batch: thin object wrappers over the C ABI (include/swmi.h)."""
 import ctypes as C
+import weakref
 
 from . import _capi
 from ._capi import Params, Timing, StreamStats, check
@@ -59,11 +60,23 @@ class Batch:
     _owned = True
 
     @classmethod
-    def _view(cls, lib, handle, n_refs, n_reads):
-        """results-only batch owned by a Stream"""
+    def _view(cls, lib, handle, n_refs, n_reads, owner):
+        """results-only batch owned by a Stream.  The view keeps the Stream alive (swmi_stream_close frees every result
+        batch), and Stream.close() invalidates it: a late call raises SwmiError instead of touching freed memory."""
         b = cls.__new__(cls)
         b._ctx, b._lib, b._h, b.n_refs, b.n_reads, b._owned = None, lib, handle, n_refs, n_reads, False
+        b._owner = owner
         return b
+
+    def __getattribute__(self, name):
+        # (a view whose Stream was closed has _h = None: every accessor passes it to the library, which must not see NULL
+        # silently turned into "batch is null" for some calls and a crash for others)
+        if name in Batch._NEEDS_HANDLE and object.__getattribute__(self, "_h") is None:
+            raise _capi.SwmiError(-1, "the batch is closed (freed, or the Stream that owned it was closed)")
+        return object.__getattribute__(self, name)
+
+    _NEEDS_HANDLE = frozenset(("run", "run_async", "wait", "timing", "pipeline_mode", "score", "n_alignments", "alignment",
+                               "alignments", "pair_results", "materialise_all", "ref_total", "ref_totals", "ref_match_sites"))
 
     def __init__(self, ctx, refs, reads):
         self._ctx = ctx
@@ -188,6 +201,7 @@ class Stream:
         h = C.c_void_p()
         check(self._lib.swmi_stream_open(ctx._h, C.byref(p), qb, qo, self.n_reads, int(slots), int(chunk_bytes), C.byref(h)))
         self._h = h
+        self._views = []                  # weak references to the result views handed out by chunks()
 
     def push(self, refs):
         rb, ro = _capi.pack(refs)
@@ -213,7 +227,9 @@ class Stream:
             b, first = C.c_void_p(), C.c_uint64()
             check(self._lib.swmi_stream_chunk(self._h, k, C.byref(b), C.byref(first)))
             n_pairs = self._lib.swmi_batch_n_pairs(b)
-            out.append((first.value, Batch._view(self._lib, b, n_pairs // max(self.n_reads, 1), self.n_reads)))
+            v = Batch._view(self._lib, b, n_pairs // max(self.n_reads, 1), self.n_reads, self)
+            self._views.append(weakref.ref(v))
+            out.append((first.value, v))
         return out
 
     def totals(self):
@@ -235,6 +251,11 @@ class Stream:
 
     def close(self):
         if getattr(self, "_h", None):
+            for w in getattr(self, "_views", []):      # the native close frees every result batch: no view may outlive it
+                v = w()
+                if v is not None:
+                    v._h = None
+            self._views = []
             self._lib.swmi_stream_close(self._h)
             self._h = None
 

@@ -79,6 +79,10 @@ struct DevBuf {
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
     template <class T> T *as() const { return (T *)p; }
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }                 // (a buffer added to a struct later cannot be forgotten by its free function)
 };
 
 struct PinnedBuf {
@@ -96,6 +100,10 @@ struct PinnedBuf {
         return SWMI_OK;
     }
     void release() { if (p) (void)hipHostFree(p); p = nullptr; dp = nullptr; cap = 0; }
+    PinnedBuf() = default;
+    PinnedBuf(const PinnedBuf &) = delete;
+    PinnedBuf &operator=(const PinnedBuf &) = delete;
+    ~PinnedBuf() { release(); }
 };
 
 // ------------------------------------------------------------------------------------------
@@ -111,8 +119,9 @@ struct swmi_ctx {
     int profiling = 0;
     uint32_t mode = 1;                      // requested pipeline (see swmi.h); mode 1 falls back to 2 for scores it cannot handle
     int zero_copy = 1;                      // kernels write results straight into pinned host memory (no D2H copy)
-    uint64_t arena_words_per_pair = 48;     // first guess of the record arena, grows on demand
-    uint64_t arena_copy_wpp = 48;           // arena words per pair fetched with the first D2H (tracks the last run)
+    uint64_t arena_words_per_pair = 160;    // first guess of the record arena (header + ops + two strings of a ~180-step alignment), grows on demand
+    uint64_t arena_copy_wpp = 160;          // arena words per pair fetched with the first D2H (tracks the last run)
+    uint64_t recs_per_pair_x16 = 32;        // first guess of the record table: entries per pair x 16, grows on demand
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     PinnedBuf h_err;                        // one host-mapped word the kernels raise on an internal failure (strip pipeline timeout)
     DevBuf d_hdr_ring;                      // arena headers of launches that run sw_tfused_kernel / sw_resident_pairs_kernel ONLY: a fresh zeroed
@@ -121,14 +130,14 @@ struct swmi_ctx {
     int64_t spin_us = 2000;                 // how long a run polls its stream for completion before it blocks (a batch is sub-millisecond)
     uint32_t dbg_strip_spins = 0;           // test knob: spin budget of the strip pipeline (0 = default)
     uint32_t dbg_reverse_strips = 0;        // test knob: strip items dispatched consumer-first
-    int auto_mode = 1;                      // choose the pipeline per batch unless "mode" was set explicitly
-    uint32_t auto_ties_x100 = 300;          // automatic mode: mode 0 when a sampled pair has this many tied maxima (x 1/100) on average
+    uint32_t auto_ties_x100 = 300;          // automatic traceback grain: split when a sampled pair has this many tied maxima (x 1/100) on average
     uint32_t col_chunks = 0;                // test knob: force this many column chunks per pair (0 = automatic)
     int tb_split = -1;                      // mode-1 traceback grain: -1 automatic, 0 one workgroup per pair, 1 one wavefront per window / alignment
     bool ext_events = false;                // SWMI_EXT_EVENTS=1: the plain two-kernel run is timed by the dispatches' own start/stop times (pure kernel
                                             // durations, as rocprofv3 shows them) -- measured 8-12 us per run DEARER than three hipEventRecord, so off
     int tfused = -1;                        // transposed sweep + traceback by one wavefront per pair (swmi_tfused.hip): -1 automatic, 0 never, 1 whenever a pair qualifies
     int resident = -1;                      // small pairs handled by one wavefront with the direction field in LDS: -1 automatic, 0 never, 1 whenever it fits
+    int device_strings = 1;                 // the traceback kernels write both aligned strings behind every record (swmi_emit.h); 0: 2-bit ops only, strings built by the host
     bool cell_cap_set = false;              // cell_cap given by the caller (otherwise small launches get longer lists)
     // swmi_batch_run_async: one run in flight on the context's own host thread
     std::thread worker;
@@ -146,8 +155,8 @@ struct HostAln {
     uint32_t rank;
     int32_t begin, end_i, end_j;
     uint32_t n_ops;
-    uint64_t ops_at;        // index into swmi_batch::ops (dwords)
-    int64_t str_id = -1;    // >= 0 once the strings are built: offset of the reference-side string in swmi_batch::str_buf
+    const uint32_t *rec = nullptr;   // the alignment's payload in the arena: packed ops [, the two strings written by the kernels]
+    int64_t str_id = -1;    // records without strings: >= 0 once the strings are built, offset of the reference-side string in swmi_batch::str_buf
 };
 
 struct PairRes {
@@ -197,6 +206,7 @@ struct swmi_batch {
     swmi_params auto_params{};
     std::vector<Work> work;                 // schedule (pairs sorted by work), valid for work_mode
     int work_mode = -1;
+    bool work_tfused = false;               // the schedule's workspace sizes leave room for sw_tfused_kernel's column checkpoints
     uint32_t eff_mode = 1;                  // pipeline of the current run
     uint64_t work_cells = 0;
     std::vector<uint8_t> pairs_on_device;   // image of the PairDesc array currently in d_pairs
@@ -225,16 +235,19 @@ struct swmi_batch {
     } prep;
     std::vector<PairRes> pairs;             // by pair index
     // raw record streams of the last run (one per launch chunk), indexed lazily on the first alignment access
-    struct RawChunk { size_t at, words; size_t lo; std::vector<uint32_t> wpos; };   // wpos: re-run chunks only
+    // the record table entries (AlnRec, swmi_device.h) and the payload arenas of the launches, one RawChunk per launch
+    struct RawChunk { size_t at, words; size_t tab_at, n_rec; size_t lo; std::vector<uint32_t> wpos; };   // wpos: re-run chunks only
     std::vector<uint32_t> raw;
+    std::vector<AlnRec> rtab;
     // a run of ONE launch with results in pinned memory leaves its record stream where the kernels wrote it (the pinned block
     // is the batch's own and lives until the next run): copied into `raw` only when something needs it there
     const uint32_t *raw_ext = nullptr;
+    const AlnRec *rtab_ext = nullptr;
     uint64_t raw_ext_records = 0, raw_ext_cap = 0;
     std::vector<RawChunk> raw_chunks;
     bool indexed = false;
+    bool rec_strings = false;               // the records of the last run carry both aligned strings (option device_strings)
     std::vector<HostAln> alns;              // grouped by pair, ordered as OptAlignments returns them
-    std::vector<uint32_t> ops;              // concatenated op words of all records
     std::vector<char> str_buf;              // every alignment's two NUL-terminated strings, at fixed offsets (str_at)
     std::vector<uint64_t> str_at;           // per alignment: offset of its reference-side string; the read side follows it
     // MapRef view cache
@@ -340,9 +353,8 @@ extern "C" int swmi_set_option(swmi_ctx *ctx, const char *name, int64_t value) {
         if (value < (1 << 20)) return fail(SWMI_ERR_INVALID, "max_workspace_bytes too small");
         ctx->max_workspace_bytes = (uint64_t)value;
     } else if (!strcmp(name, "mode")) {
-        // -1: automatic (the default): mode 1, or mode 0 for batches where most pairs carry many tied maxima
+        // -1 is the same as 1 (kept for callers that passed "automatic": mode 0 was measured and is never faster)
         if (value < -1 || value > 2) return fail(SWMI_ERR_INVALID, "mode must be -1 (automatic), 0, 1 or 2");
-        ctx->auto_mode = value < 0;
         ctx->mode = value < 0 ? 1u : (uint32_t)value;
     } else if (!strcmp(name, "auto_ties_x100")) {
         if (value < 100) return fail(SWMI_ERR_INVALID, "auto_ties_x100 out of range");
@@ -360,6 +372,8 @@ extern "C" int swmi_set_option(swmi_ctx *ctx, const char *name, int64_t value) {
     } else if (!strcmp(name, "resident")) {
         if (value < -1 || value > 1) return fail(SWMI_ERR_INVALID, "resident must be -1 (automatic), 0 or 1");
         ctx->resident = (int)value;
+    } else if (!strcmp(name, "device_strings")) {
+        ctx->device_strings = value != 0;
     } else if (!strcmp(name, "tb_split")) {
         if (value < -1 || value > 1) return fail(SWMI_ERR_INVALID, "tb_split must be -1 (automatic), 0 or 1");
         ctx->tb_split = (int)value;
@@ -445,6 +459,7 @@ extern "C" void swmi_batch_free(swmi_ctx *ctx, swmi_batch *b) {
     b->d_dir.release(); b->d_seam.release(); b->d_result.release(); b->d_cells.release();
     b->d_cells_off.release(); b->d_cells_cap.release(); b->d_dbg.release(); b->d_dbg2.release();
     b->d_strip_items.release(); b->d_progress.release(); b->d_col_items.release(); b->d_win_off.release(); b->d_queue.release(); b->d_res_items.release();
+    b->d_tf_items.release();
     b->h_result.release();
     delete b;
 }
@@ -472,11 +487,14 @@ static int upload_device(swmi_ctx *ctx, swmi_batch *b, hipStream_t st, const uin
     if (ref_total) HIP_TRY(hipMemcpyAsync(raw, ref_src, ref_total, hipMemcpyHostToDevice, st));
     if (read_total) HIP_TRY(hipMemcpyAsync(raw + read_base, read_src, read_total, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(roff, b->ref_off.data(), ((size_t)n_refs + 1) * 8, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(roff + n_refs + 1, b->read_off.data(), ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice, st));
+    // (the reads' offsets are stored absolute -- from the start of `raw` -- so that one base pointer serves both sides)
+    std::vector<uint64_t> read_abs(b->read_off);
+    for (auto &o : read_abs) o += read_base;
+    HIP_TRY(hipMemcpyAsync(roff + n_refs + 1, read_abs.data(), ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice, st));
     if (n_refs) HIP_TRY(hipMemcpyAsync(b->d_refs.p, b->ref_desc.data(), n_refs * sizeof(SeqDesc), hipMemcpyHostToDevice, st));
     if (n_reads) HIP_TRY(hipMemcpyAsync(b->d_reads.p, b->read_desc.data(), n_reads * sizeof(SeqDesc), hipMemcpyHostToDevice, st));
     HIP_TRY(swmi_launch_encode(raw, roff, b->d_refs.as<SeqDesc>(), b->d_seqw.as<uint32_t>(), ctx->d_lut.as<uint8_t>(), n_refs, st));
-    HIP_TRY(swmi_launch_encode(raw + read_base, roff + n_refs + 1, b->d_reads.as<SeqDesc>(), b->d_seqw.as<uint32_t>(),
+    HIP_TRY(swmi_launch_encode(raw, roff + n_refs + 1, b->d_reads.as<SeqDesc>(), b->d_seqw.as<uint32_t>(),
                                ctx->d_lut.as<uint8_t>(), n_reads, st));
     HIP_TRY(hipStreamSynchronize(st));
     // a new set of sequences invalidates everything derived from the old one
@@ -529,12 +547,19 @@ struct RunState {
     double enqueue_us = 0, wait_us = 0, copyout_us = 0;
     bool one_wave_sweep = false;            // the strip pipeline gave up once in this run: long reads are swept by one wavefront
     bool tb_split = false;                  // mode 1: detect per window + walk per alignment instead of one workgroup per pair
-    bool defer_copy = false;                // this launch is the whole run: its record stream may stay in the pinned block
+    bool defer_copy = false;                // this launch is the whole run: its records may stay in the pinned block
+    bool keep = true;                       // the launch's records belong to the batch's results (false: the sampled pre-pass)
 };
 
 // layout of the device result block: [ArenaHdr | PairOut x np | arena words ...]
 inline size_t result_out_off() { return 64; }
-inline size_t result_arena_off(size_t np) { return (64 + np * sizeof(PairOut) + 255) & ~(size_t)255; }
+// layout of the result block: [ArenaHdr | PairOut x np | record table, tab_cap entries | arena words ...]
+inline size_t result_tab_off(size_t np) { return (64 + np * sizeof(PairOut) + 255) & ~(size_t)255; }
+inline size_t result_arena_off(size_t np, uint64_t tab_cap) { return (result_tab_off(np) + tab_cap * sizeof(AlnRec) + 255) & ~(size_t)255; }
+// dwords of one alignment's payload: ops packed 16 per dword [+ the two strings, n_ops / 4 + 1 dwords each (swmi_emit.h)]
+inline uint64_t rec_words(uint32_t n_ops, bool strings) {
+    return ((uint64_t)n_ops + 15) / 16 + (strings ? 2 * ((uint64_t)n_ops / 4 + 1) : 0);
+}
 
 }  // namespace
 
@@ -561,8 +586,7 @@ static uint64_t traceback_lds_bytes(uint32_t mode, uint64_t max_path, uint64_t m
 // Runs fill + traceback for `work` (already ordered), one chunk, and parses the records.
 // per-pair cell-list geometry: uniform (cap) when cells_cap_exact is empty, else exact per pair.
 static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, size_t hi,
-                     const std::vector<uint64_t> *cells_exact,
-                     std::vector<PairOut> &outs, std::vector<uint32_t> &arena_copy, uint64_t &arena_used) {
+                     const std::vector<uint64_t> *cells_exact, std::vector<PairOut> &outs) {
     swmi_ctx *ctx = rs.ctx;
     swmi_batch *b = rs.b;
     const size_t np = hi - lo;
@@ -616,7 +640,8 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
         const uint32_t R_ = swmi_rows_per_lane(m_), lact = (m_ + R_ - 1) / R_;
         const uint64_t nblk = ((uint64_t)n_ + lact - 1 + 15) / 16, n_ck = (nblk + SWMI_CK_BLOCKS - 1) / SWMI_CK_BLOCKS;
         opw = (uint32_t)((path_bound(n_, m_, P) + 15) / 16 + 1);
-        return nblk * R_ * 64 + ((n_ck + 1) & ~1ull) + 2ull * res_cell_cap + 64ull * opw + (n_ + 3) / 4 + 1 + (m_ + 3) / 4 + 1 + 8;
+        return nblk * R_ * 64 + ((n_ck + 1) & ~1ull) + 2ull * res_cell_cap + 64ull * opw + (n_ + 3) / 4 + 1 + (m_ + 3) / 4 + 1 + 8 +
+               128;                                           // (SWMI_EMIT_SCRATCH_WORDS: the string scratch of swmi_emit.h)
     };
     bool res_maybe = false;
     if (res_possible)
@@ -642,6 +667,7 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
     const uint64_t chunk_budget = ctx->col_chunks > 1 ? ctx->col_chunks : std::max<uint64_t>(1, 1024 / std::max<size_t>(np, 1));
     pd.resize(np);
     if (b->eff_mode == 1) win_off.resize(np + 1);
+    uint32_t pb_m = 0xFFFFFFFFu, pb_n = 0xFFFFFFFFu, pb_val = 0;
     for (size_t k = 0; k < np; k++) {
         const Work &w = work[lo + k];
         PairDesc d{};
@@ -709,7 +735,8 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
             }
         }
         pd[k] = d;
-        max_path = std::max<uint32_t>(max_path, (uint32_t)path_bound(n_, m_, b->params));
+        if (m_ != pb_m || n_ != pb_n) { pb_m = m_; pb_n = n_; pb_val = (uint32_t)path_bound(n_, m_, b->params); }   // (runs of equal lengths)
+        max_path = std::max<uint32_t>(max_path, pb_val);
         max_read = std::max(max_read, m_);
     }
     n_strip_items = strip_items.size();
@@ -817,9 +844,12 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
 
     const auto c0 = std::chrono::steady_clock::now();
     uint64_t arena_cap = std::max<uint64_t>(np * ctx->arena_words_per_pair, 1024);
+    uint64_t tab_cap = std::max<uint64_t>(np * ctx->recs_per_pair_x16 / 16 + 64, 256);
     std::vector<uint8_t> saved_outs;       // PairOut block carried across an arena re-allocation
     for (int attempt = 0;; attempt++) {
-        const size_t a_off = result_arena_off(np);
+        // (an overflow that growing cannot cure -- a path longer than the staging area -- must not retry for ever)
+        if (attempt > 4) return fail(SWMI_ERR_HIP, "the record arena overflowed %d times in a row; results discarded", attempt);
+        const size_t t_off = result_tab_off(np), a_off = result_arena_off(np, tab_cap);
         if ((rc = b->d_result.reserve(a_off + arena_cap * 4))) return rc;
         uint8_t *res = b->d_result.as<uint8_t>();
         if (attempt > 0) {         // (on the first attempt the fill kernel zeroes the arena header itself)
@@ -873,6 +903,8 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
         ta.hdr = (ArenaHdr *)res;
         ta.arena = (uint32_t *)(res + a_off);
         ta.arena_cap_words = arena_cap;
+        ta.rec_tab = (AlnRec *)(res + t_off);
+        ta.rec_tab_cap = (uint32_t)std::min<uint64_t>(tab_cap, 0xFFFFFFFFu);
         ta.n_pairs = fa.n_pairs; ta.cell_cap = fa.cell_cap;
         ta.match = fa.match; ta.mismatch = fa.mismatch; ta.gap = fa.gap; ta.strict = fa.strict;
         ta.lds_words = lds_words;
@@ -881,8 +913,15 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
         ta.pad2 = 0;
         ta.lds_read_words = lds_read_words;
         ta.out_host = nullptr;
-        ta.ovf_host = nullptr;
+        // (without zero-copy results the kernels' give-up codes still need a host-visible word: the context's own)
+        ta.ovf_host = (uint32_t *)ctx->h_err.dp + 4;
+        ((volatile uint32_t *)ctx->h_err.p)[4] = 0u; ((volatile uint32_t *)ctx->h_err.p)[5] = 0u;
         ta.win_off = nullptr; ta.q_count = nullptr; ta.q_items = nullptr; ta.q_cap = 0; ta.pad4 = 0;
+        const bool strings = ctx->device_strings != 0 && b->d_raw.p != nullptr;
+        ta.raw = strings ? b->d_raw.as<uint8_t>() : nullptr;
+        ta.raw_off = strings ? b->d_raw_off.as<uint64_t>() : nullptr;
+        ta.raw_reads_at = b->n_refs + 1u;
+        b->rec_strings = strings;
         ResidentArgs xa;
         xa.res_items = n_res ? b->d_res_items.as<uint32_t>() : nullptr;
         xa.n_res = (uint32_t)n_res; xa.res_lds_words = res_lds_words; xa.res_cell_cap = res_cell_cap; xa.res_ops_words = res_ops_words;
@@ -893,7 +932,7 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
         xt.tile_words = ((tf_max_m + 63u + 15u) / 16u) * 64u * SWMI_TF_BR;
         xt.ref_words = (tf_max_n + 3u) / 4u + 1u;
         xt.read_words = (tf_max_m + 3u) / 4u + 1u;
-        xt.stage_words = (tf_max_path + 3u) / 4u + 1u;
+        xt.stage_words = (tf_max_path + 3u) / 4u + 1u + 128u;          // (+ SWMI_EMIT_SCRATCH_WORDS: swmi_emit.h)
         static const bool tf_marks = getenv("SWMI_DEBUG_MARKS") != nullptr;
         xt.debug_marks = tf_marks ? 1u : 0u;
         xt.lds_words = (xt.tile_words + 2u * xt.cell_cap + xt.stage_words + xt.ref_words + xt.read_words + 3u) & ~3u;
@@ -913,6 +952,7 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
             ta.ovf_host = (uint32_t *)hd;
             ta.out_host = (PairOut *)(hd + result_out_off());
             ta.arena = (uint32_t *)(hd + a_off);
+            ta.rec_tab = (AlnRec *)(hd + t_off);
         }
         ta.dbg = nullptr;
         if (dbg_fill) {
@@ -970,11 +1010,13 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
 
         // without zero-copy: one D2H of header + pair outputs + as much of the arena as the previous run used
         // (plus slack); the rare remainder is fetched after the header has been read
+        // (header, pair outputs and as many table entries and arena words as the previous run used, plus slack)
         const uint64_t copy_words = std::min<uint64_t>(arena_cap, std::max<uint64_t>(256, np * ctx->arena_copy_wpp));
-        const size_t copy_bytes = a_off + copy_words * 4;
+        const uint64_t copy_recs = std::min<uint64_t>(tab_cap, np * ctx->recs_per_pair_x16 / 16 + 64);
         if (!zc) {
             if ((rc = b->h_result.reserve(a_off + arena_cap * 4))) return rc;
-            HIP_TRY(hipMemcpyAsync(b->h_result.p, res, copy_bytes, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipMemcpyAsync(b->h_result.p, res, t_off + copy_recs * sizeof(AlnRec), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipMemcpyAsync((uint8_t *)b->h_result.p + a_off, res + a_off, copy_words * 4, hipMemcpyDeviceToHost, ctx->stream));
             if (ctx->profiling) HIP_TRY(hipEventRecord(ctx->ev[4], ctx->stream));
         }
         static const char *watchdog = getenv("SWMI_DEBUG_WATCHDOG");      // diagnostics: give up on a launch that does not end, show the kernel's marks
@@ -1000,9 +1042,10 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
             if (q != hipSuccess) HIP_TRY(hipStreamSynchronize(ctx->stream));
         }
         const auto c2 = std::chrono::steady_clock::now();
-        if (zc && ((const volatile uint32_t *)b->h_result.p)[1] != 0u) {      // sw_tfused_kernel gave up a wait that cannot last (never seen)
-            const uint32_t code = ((const volatile uint32_t *)b->h_result.p)[1];
-            ((volatile uint32_t *)b->h_result.p)[1] = 0u;
+        volatile uint32_t *giveup = zc ? (volatile uint32_t *)b->h_result.p + 1 : (volatile uint32_t *)ctx->h_err.p + 5;
+        if (*giveup != 0u) {      // sw_tfused_kernel gave up a wait that cannot last (never seen)
+            const uint32_t code = *giveup;
+            *giveup = 0u;
             return fail(SWMI_ERR_HIP, "sw_tfused_kernel: internal wait abandoned (code %08x); results discarded", code);
         }
         if (*(volatile uint32_t *)ctx->h_err.p != 0u) {
@@ -1014,7 +1057,7 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
                 return fail(SWMI_ERR_HIP, "the sweep raised its error flag without the strip pipeline; results discarded");
             rs.one_wave_sweep = true;
             b->timing.strip_fallbacks++;
-            return run_chunk(rs, work, lo, hi, cells_exact, outs, arena_copy, arena_used);
+            return run_chunk(rs, work, lo, hi, cells_exact, outs);
         }
         rs.enqueue_us += std::chrono::duration<double, std::micro>(c1 - c0).count();
         rs.wait_us += std::chrono::duration<double, std::micro>(c2 - c1).count();
@@ -1114,7 +1157,7 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
                 hdr = &hdr_copy;
             }
         } else {
-            overflow = hdr->used_words > arena_cap;
+            overflow = hdr->used_words > arena_cap || hdr->n_records > tab_cap;
         }
         if (overflow) {            // records were dropped: grow to the exact need and redo the traceback
             if (zc) {
@@ -1129,123 +1172,131 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
                 // the split traceback counts a pair's cells by atomics and flags list overflows itself: start both over
                 if (split && !(so.flags & SWMI_F_DEGENERATE)) { so.n_cells = 0; so.flags &= ~SWMI_F_CELL_OVF; }
             }
-            arena_cap = hdr->used_words + 1024;
+            arena_cap = std::max<uint64_t>(arena_cap, hdr->used_words + 1024);
+            tab_cap = std::max<uint64_t>(tab_cap, hdr->n_records + 64);
             ctx->arena_words_per_pair = std::max<uint64_t>(ctx->arena_words_per_pair, arena_cap / np + 1);
+            ctx->recs_per_pair_x16 = std::max<uint64_t>(ctx->recs_per_pair_x16, tab_cap * 16 / np + 1);
             continue;
         }
         outs.assign((const PairOut *)(h + result_out_off()), (const PairOut *)(h + result_out_off()) + np);
-        if (zc) {
-            // the records are contiguous from word 0; how many there are follows from the pair outputs
-            uint64_t expect = 0, at = 0;
-            for (auto &o : outs)
-                if (!(o.flags & (SWMI_F_DEGENERATE | SWMI_F_CELL_OVF))) expect += o.n_cells;
-            const uint32_t *aw = (const uint32_t *)(h + a_off);
-            if (rs.defer_copy && &arena_copy == &b->raw && arena_copy.empty()) {
-                // the only launch of the run: the stream stays in the pinned block, and how long it is -- a walk from record to
-                // record, 6 us per 1000 pairs -- is found out when something needs it in the batch's vector (settle_raw)
-                b->raw_ext = aw; b->raw_ext_records = expect; b->raw_ext_cap = arena_cap;
-                arena_used = 0;
-                for (auto &o : outs) o.flags &= ~SWMI_F_ARENA_OVF;
-                rs.copyout_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - c2).count();
-                return SWMI_OK;
-            }
-            for (uint64_t k = 0; k < expect; k++) {
-                if (at + SWMI_ALNREC_WORDS > arena_cap) return fail(SWMI_ERR_HIP, "record stream overruns the arena");
-                at += SWMI_ALNREC_WORDS + ((uint64_t)aw[at + 5] + 15) / 16;
-            }
-            if (at > arena_cap) return fail(SWMI_ERR_HIP, "record stream overruns the arena");
-            arena_used = at;
-        } else {
-            arena_used = hdr->used_words;
-            if (arena_used > copy_words)
-                HIP_TRY(hipMemcpy((uint8_t *)b->h_result.p + copy_bytes, res + copy_bytes, (arena_used - copy_words) * 4,
-                                  hipMemcpyDeviceToHost));
-            ctx->arena_copy_wpp = arena_used * 5 / (4 * np) + 2;
-        }
-        // the record stream is appended to the caller's vector (the batch's raw stream): one copy out of the pinned block --
-        // or, for the only launch of a run, left in the pinned block (settle_raw)
-        arena_copy.insert(arena_copy.end(), (const uint32_t *)(h + a_off), (const uint32_t *)(h + a_off) + arena_used);
         for (auto &o : outs) o.flags &= ~SWMI_F_ARENA_OVF;
+        // how many records there are follows from the pair outputs (zero-copy: the header sits in device memory)
+        uint64_t n_rec = 0;
+        if (zc) {
+            for (auto &o : outs)
+                if (!(o.flags & (SWMI_F_DEGENERATE | SWMI_F_CELL_OVF))) n_rec += o.n_cells;
+        } else {
+            n_rec = hdr->n_records;
+        }
+        if (n_rec > tab_cap) return fail(SWMI_ERR_HIP, "more records than the table holds");
+        const AlnRec *tab = (const AlnRec *)(h + t_off);
+        const uint32_t *aw = (const uint32_t *)(h + a_off);
+        if (!zc) {
+            if (n_rec > copy_recs)
+                HIP_TRY(hipMemcpy((uint8_t *)b->h_result.p + t_off + copy_recs * sizeof(AlnRec), res + t_off + copy_recs * sizeof(AlnRec),
+                                  (n_rec - copy_recs) * sizeof(AlnRec), hipMemcpyDeviceToHost));
+            if (hdr->used_words > copy_words)
+                HIP_TRY(hipMemcpy((uint8_t *)b->h_result.p + a_off + copy_words * 4, res + a_off + copy_words * 4,
+                                  (hdr->used_words - copy_words) * 4, hipMemcpyDeviceToHost));
+            ctx->arena_copy_wpp = hdr->used_words * 5 / (4 * np) + 2;
+            ctx->recs_per_pair_x16 = std::max<uint64_t>(ctx->recs_per_pair_x16, n_rec * 20 / np + 1);
+        }
+        if (!rs.keep) return SWMI_OK;
+        if (rs.defer_copy && b->raw_chunks.empty()) {
+            // the only launch of the run: table and payloads stay in the pinned block (the batch's own until the next run)
+            // and are indexed there when something asks for an alignment
+            b->raw_ext = aw; b->rtab_ext = tab; b->raw_ext_records = n_rec; b->raw_ext_cap = arena_cap;
+            b->raw_chunks.push_back(swmi_batch::RawChunk{0, 0, 0, (size_t)n_rec, lo, {}});
+            rs.copyout_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - c2).count();
+            return SWMI_OK;
+        }
+        // several launches in one run: each one's table and payloads are copied out of the pinned block, which the next
+        // launch writes again.  The table is dense: its sequential read also tells how much of the arena is in use.
+        uint64_t used = 0;
+        for (uint64_t k = 0; k < n_rec; k++) {
+            const uint64_t end = (((uint64_t)tab[k].off_hi << 32) | tab[k].off_lo) + rec_words(tab[k].n_ops, b->rec_strings);
+            used = std::max(used, end);
+        }
+        if (used > arena_cap) return fail(SWMI_ERR_HIP, "record payloads overrun the arena");
+        b->raw_chunks.push_back(swmi_batch::RawChunk{b->raw.size(), (size_t)used, b->rtab.size(), (size_t)n_rec, lo, {}});
+        b->raw.insert(b->raw.end(), aw, aw + used);
+        b->rtab.insert(b->rtab.end(), tab, tab + n_rec);
         rs.copyout_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - c2).count();
         return SWMI_OK;
     }
 }
 
-// the record stream left in the pinned block moves into the batch's own vector
+// the records left in the pinned block move into the batch's own vectors (before the block is written again)
 static int settle_raw(swmi_batch *b) {
     if (!b->raw_ext) return SWMI_OK;
     const uint32_t *aw = b->raw_ext;
-    b->raw_ext = nullptr;
-    uint64_t at = 0;
-    for (uint64_t k = 0; k < b->raw_ext_records; k++) {
-        if (at + SWMI_ALNREC_WORDS > b->raw_ext_cap) return fail(SWMI_ERR_HIP, "record stream overruns the arena");
-        at += SWMI_ALNREC_WORDS + ((uint64_t)aw[at + 5] + 15) / 16;
-    }
-    if (at > b->raw_ext_cap) return fail(SWMI_ERR_HIP, "record stream overruns the arena");
-    b->raw.assign(aw, aw + at);
-    if (b->raw_chunks.size() == 1) b->raw_chunks[0].words = (size_t)at;
+    const AlnRec *tab = b->rtab_ext;
+    b->raw_ext = nullptr; b->rtab_ext = nullptr;
+    uint64_t used = 0;
+    for (uint64_t k = 0; k < b->raw_ext_records; k++)
+        used = std::max(used, (((uint64_t)tab[k].off_hi << 32) | tab[k].off_lo) + rec_words(tab[k].n_ops, b->rec_strings));
+    if (used > b->raw_ext_cap) return fail(SWMI_ERR_HIP, "record payloads overrun the arena");
+    b->raw.assign(aw, aw + used);
+    b->rtab.assign(tab, tab + b->raw_ext_records);
+    if (b->raw_chunks.size() == 1) { b->raw_chunks[0].at = 0; b->raw_chunks[0].words = (size_t)used; b->raw_chunks[0].tab_at = 0; }
     return SWMI_OK;
 }
 
-// records of one chunk -> per-pair lists (tmp, keyed by position in `work`)
-struct ParsedRec { uint32_t wpos; HostAln a; };
-
-static int parse_records(const uint32_t *arena, uint64_t used, size_t lo, const std::vector<uint32_t> *wpos_map,
-                         std::vector<uint32_t> &ops, std::vector<ParsedRec> &recs) {
-    uint64_t at = 0;
-    while (at < used) {
-        if (at + SWMI_ALNREC_WORDS > used) return fail(SWMI_ERR_HIP, "truncated record in arena");
-        const uint32_t *w = arena + at;
-        ParsedRec r;
-        r.wpos = wpos_map ? (*wpos_map)[w[0]] : (uint32_t)(lo + w[0]);
-        r.a.rank = w[1];
-        r.a.begin = (int32_t)w[2];
-        r.a.end_i = (int32_t)w[3];
-        r.a.end_j = (int32_t)w[4];
-        r.a.n_ops = w[5];
-        const uint64_t opw = ((uint64_t)r.a.n_ops + 15) / 16;
-        if (at + SWMI_ALNREC_WORDS + opw > used) return fail(SWMI_ERR_HIP, "record overruns arena");
-        r.a.ops_at = ops.size();
-        ops.insert(ops.end(), w + SWMI_ALNREC_WORDS, w + SWMI_ALNREC_WORDS + opw);
-        recs.push_back(r);
-        at += SWMI_ALNREC_WORDS + opw;
-    }
-    return SWMI_OK;
-}
-
-// Turns the raw record streams of the last run into per-pair alignment lists (first use of an alignment accessor).
+// Turns the record tables of the last run into per-pair alignment lists (first use of an alignment accessor).
 static int ensure_indexed(swmi_batch *b) {
     if (b->indexed) return SWMI_OK;
-    { int rc0 = settle_raw(b); if (rc0) return rc0; }
     const std::vector<Work> &work = b->work;
-    std::vector<ParsedRec> recs;
-    b->ops.clear();
+    // every launch's table (dense, read sequentially) with the arena its payload offsets refer to; the only launch of a
+    // run may still sit in the pinned block the kernels wrote: indexed where it is, nothing copied
+    struct Src { const AlnRec *tab; uint64_t n_rec; const uint32_t *arena; uint64_t words; const swmi_batch::RawChunk *c; };
+    std::vector<Src> srcs;
     for (auto &c : b->raw_chunks) {
-        int rc = parse_records(b->raw.data() + c.at, c.words, c.lo, c.wpos.empty() ? nullptr : &c.wpos, b->ops, recs);
-        if (rc) return rc;
+        if (b->raw_ext) srcs.push_back(Src{b->rtab_ext, b->raw_ext_records, b->raw_ext, b->raw_ext_cap, &c});
+        else            srcs.push_back(Src{b->rtab.data() + c.tab_at, c.n_rec, b->raw.data() + c.at, c.words, &c});
     }
-    // group records by pair, ordered as OptAlignments lists them: by the rank the traceback kernel computed, or -- records
-    // of the split traceback, which come in any order -- by their cell: row-major (SmithWaterman.java:157-185), or per
-    // anti-diagonal with ascending j for the strict mode (DistributedSW.java:209-239)
+    auto wpos_of = [](const Src &sr, uint32_t out_id) -> uint64_t {
+        return sr.c->wpos.empty() ? sr.c->lo + out_id : (out_id < sr.c->wpos.size() ? sr.c->wpos[out_id] : ~0ull);
+    };
     for (auto &w : work) b->pairs[w.pair].count = 0;
-    for (auto &r : recs) b->pairs[work[r.wpos].pair].count++;
+    uint64_t total = 0;
+    for (auto &sr : srcs) {
+        for (uint64_t k = 0; k < sr.n_rec; k++) {
+            const uint64_t wp = wpos_of(sr, sr.tab[k].out_id);
+            if (wp >= work.size()) return fail(SWMI_ERR_HIP, "record of an unknown pair");
+            b->pairs[work[wp].pair].count++;
+        }
+        total += sr.n_rec;
+    }
     uint64_t run = 0;
     for (auto &w : work) { PairRes &pr = b->pairs[w.pair]; pr.first = run; run += pr.count; }
+    if (run != total) return fail(SWMI_ERR_HIP, "record count mismatch");
     b->alns.assign(run, HostAln{});
     std::vector<uint32_t> cursor;
     const bool strict = b->params.tie_mode == SWMI_TIE_STRICT;
-    for (auto &r : recs) {
-        PairRes &pr = b->pairs[work[r.wpos].pair];
-        if (r.a.rank == SWMI_RANK_BY_CELL) {
-            if (cursor.empty()) cursor.assign(work.size(), 0u);
-            uint32_t &c = cursor[r.wpos];
-            if (c >= pr.count) return fail(SWMI_ERR_HIP, "more records than counted for a pair");
-            b->alns[pr.first + c++] = r.a;
-        } else {
-            if (r.a.rank >= pr.count) return fail(SWMI_ERR_HIP, "record rank %u out of range", r.a.rank);
-            b->alns[pr.first + r.a.rank] = r.a;
+    for (auto &sr : srcs) {
+        for (uint64_t k = 0; k < sr.n_rec; k++) {
+            const AlnRec &e = sr.tab[k];
+            const uint64_t wp = wpos_of(sr, e.out_id);
+            PairRes &pr = b->pairs[work[wp].pair];
+            const uint64_t off = ((uint64_t)e.off_hi << 32) | e.off_lo;
+            if (off + rec_words(e.n_ops, b->rec_strings) > sr.words) return fail(SWMI_ERR_HIP, "record payload overruns the arena");
+            HostAln a;
+            a.rank = e.rank; a.begin = e.begin; a.end_i = e.end_i; a.end_j = e.end_j; a.n_ops = e.n_ops;
+            a.rec = sr.arena + off;
+            // records of the split traceback come in any order: placed as they come, ordered by their cell below
+            if (e.rank == SWMI_RANK_BY_CELL) {
+                if (cursor.empty()) cursor.assign(work.size(), 0u);
+                uint32_t &c = cursor[wp];
+                if (c >= pr.count) return fail(SWMI_ERR_HIP, "more records than counted for a pair");
+                b->alns[pr.first + c++] = a;
+            } else {
+                if (e.rank >= pr.count) return fail(SWMI_ERR_HIP, "record rank %u out of range", e.rank);
+                b->alns[pr.first + e.rank] = a;
+            }
         }
     }
+    // ordered as OptAlignments lists them: by the rank the traceback kernel computed, or by cell: row-major
+    // (SmithWaterman.java:157-185), or per anti-diagonal with ascending j for the strict mode (DistributedSW.java:209-239)
     for (size_t wi = 0; wi < work.size(); wi++) {
         PairRes &pr = b->pairs[work[wi].pair];
         if (!(pr.flags & SWMI_PAIR_DEGENERATE) && pr.count != pr.n_cells)
@@ -1266,11 +1317,14 @@ static int ensure_indexed(swmi_batch *b) {
             std::stable_sort(b->alns.begin() + pr.first, b->alns.begin() + pr.first + pr.count,
                              [](const HostAln &x, const HostAln &y) { return x.begin < y.begin; });
     }
-    // one buffer for all strings (two mallocs per alignment cost more than filling them)
-    b->str_at.resize(run);
-    uint64_t chars = 0;
-    for (uint64_t k = 0; k < run; k++) { b->alns[k].str_id = -1; b->str_at[k] = chars; chars += 2ull * (b->alns[k].n_ops + 1); }
-    b->str_buf.resize(chars);
+    if (!b->rec_strings) {
+        // records without strings (option device_strings = 0): one buffer for all strings the host builds (two mallocs per
+        // alignment cost more than filling them)
+        b->str_at.resize(run);
+        uint64_t chars = 0;
+        for (uint64_t k = 0; k < run; k++) { b->alns[k].str_id = -1; b->str_at[k] = chars; chars += 2ull * (b->alns[k].n_ops + 1); }
+        b->str_buf.resize(chars);
+    }
     b->indexed = true;
     return SWMI_OK;
 }
@@ -1301,9 +1355,9 @@ extern "C" int swmi_batch_run(swmi_ctx *ctx, swmi_batch *b, const swmi_params *p
     const uint32_t n_refs = b->n_refs, n_reads = b->n_reads;
     const uint64_t n_pairs = (uint64_t)n_refs * n_reads;
     b->pairs.assign(n_pairs, PairRes{});
-    b->alns.clear(); b->ops.clear(); b->str_at.clear();
-    b->raw.clear(); b->raw_chunks.clear(); b->indexed = false;
-    b->raw_ext = nullptr;
+    b->alns.clear(); b->str_at.clear();
+    b->raw.clear(); b->rtab.clear(); b->raw_chunks.clear(); b->indexed = false;
+    b->raw_ext = nullptr; b->rtab_ext = nullptr;
     if (b->views_built || b->ref_view_ready.size() != n_refs) {     // (a run nobody read MapRef views of leaves them as they are)
         b->ref_view_ready.assign(n_refs, 0);
         b->ref_sites.assign(n_refs, {});
@@ -1340,10 +1394,9 @@ extern "C" int swmi_batch_run(swmi_ctx *ctx, swmi_batch *b, const swmi_params *p
             RunState rs0;
             rs0.ctx = ctx; rs0.b = b;
             rs0.tb_split = true;                      // (48 pairs: a small launch)
+            rs0.keep = false;                         // (its records are not results)
             std::vector<PairOut> o0;
-            std::vector<uint32_t> a0;
-            uint64_t u0 = 0;
-            int rc = run_chunk(rs0, sample, 0, sample.size(), nullptr, o0, a0, u0);
+            int rc = run_chunk(rs0, sample, 0, sample.size(), nullptr, o0);
             if (rc) return rc;
             uint64_t cells = 0, live = 0;
             for (auto &o : o0)
@@ -1364,26 +1417,54 @@ extern "C" int swmi_batch_run(swmi_ctx *ctx, swmi_batch *b, const swmi_params *p
         if (traceback_lds_bytes(0, path_bound(max_n, max_m, *p), max_m) > 160ull * 1024)
             b->eff_mode = (p->mismatch > 0 || p->gap > 0) ? 2u : 1u;
     }
-    if (b->work_mode != (int)b->eff_mode) {
+    if (b->work_mode != (int)b->eff_mode || b->work_tfused != (ctx->tfused == 1)) {
+        b->work_tfused = ctx->tfused == 1;
         b->work.clear();
         b->work.reserve(n_pairs);
         b->work_cells = 0;
-        for (uint32_t r = 0; r < n_refs; r++) {
-            const uint32_t n = b->ref_desc[r].len;
-            for (uint32_t q = 0; q < n_reads; q++) {
+        // Longest first: the tail of a launch is made of short pairs.  The schedule depends on the LENGTHS only, so the two
+        // sides are ordered by length once (n_refs log n_refs + n_reads log n_reads) and the pairs generated in that order --
+        // by cells, exactly, whenever one side has a single length (one read, or a FASTA file of equal reads), else by
+        // reference length first -- instead of sorting 10^6..10^8 pair records.
+        std::vector<uint32_t> ro(n_refs), qo(n_reads);
+        std::iota(ro.begin(), ro.end(), 0u);
+        std::iota(qo.begin(), qo.end(), 0u);
+        std::stable_sort(ro.begin(), ro.end(), [&](uint32_t a, uint32_t c) { return b->ref_desc[a].len > b->ref_desc[c].len; });
+        std::stable_sort(qo.begin(), qo.end(), [&](uint32_t a, uint32_t c) { return b->read_desc[a].len > b->read_desc[c].len; });
+        const bool refs_uniform = n_refs && b->ref_desc[ro.front()].len == b->ref_desc[ro.back()].len;
+        auto add = [&](uint32_t r, uint32_t q, uint32_t n, uint32_t m, uint64_t dw, uint64_t sw) {
+            Work w;
+            w.pair = r * n_reads + q;
+            w.cells = (uint64_t)m * n;
+            w.dir_words = dw; w.seam_words = sw;
+            b->work_cells += w.cells;
+            b->work.push_back(w);
+        };
+        const bool tf = ctx->tfused == 1;
+        if (refs_uniform) {                              // (reads outermost: descending m x the one n)
+            for (uint32_t q : qo) {
                 const uint32_t m = b->read_desc[q].len;
-                if (m == 0 || n == 0) continue;
-                Work w;
-                w.pair = r * n_reads + q;
-                w.cells = (uint64_t)m * n;
-                w.dir_words = swmi_dir_words(m, n, b->eff_mode);
-                w.seam_words = swmi_seam_words(m, n);
-                b->work_cells += w.cells;
-                b->work.push_back(w);
+                if (m == 0) continue;
+                const uint32_t n = n_refs ? b->ref_desc[ro[0]].len : 0;
+                if (n == 0) break;
+                const uint64_t dw = swmi_dir_words(m, n, b->eff_mode, tf), sw = swmi_seam_words(m, n);
+                for (uint32_t r : ro) add(r, q, n, m, dw, sw);
+            }
+        } else {
+            uint32_t last_m = 0xFFFFFFFFu;
+            uint64_t dw = 0, sw = 0;
+            for (uint32_t r : ro) {
+                const uint32_t n = b->ref_desc[r].len;
+                if (n == 0) continue;
+                last_m = 0xFFFFFFFFu;
+                for (uint32_t q : qo) {
+                    const uint32_t m = b->read_desc[q].len;
+                    if (m == 0) continue;
+                    if (m != last_m) { dw = swmi_dir_words(m, n, b->eff_mode, tf); sw = swmi_seam_words(m, n); last_m = m; }
+                    add(r, q, n, m, dw, sw);
+                }
             }
         }
-        // longest first: the tail of the launch is made of short pairs
-        std::stable_sort(b->work.begin(), b->work.end(), [](const Work &a, const Work &c) { return a.cells > c.cells; });
         b->work_mode = (int)b->eff_mode;
     }
     const std::vector<Work> &work = b->work;
@@ -1411,10 +1492,8 @@ extern "C" int swmi_batch_run(swmi_ctx *ctx, swmi_batch *b, const swmi_params *p
             hi++;
         }
         dir_bytes += words * 4;
-        uint64_t used = 0;
-        const size_t raw_at = b->raw.size();
         rs.defer_copy = lo == 0 && hi == work.size();
-        int rc = run_chunk(rs, work, lo, hi, nullptr, outs, b->raw, used);
+        int rc = run_chunk(rs, work, lo, hi, nullptr, outs);
         rs.defer_copy = false;
         if (rc) return rc;
         for (size_t k = 0; k < hi - lo; k++) {
@@ -1424,7 +1503,6 @@ extern "C" int swmi_batch_run(swmi_ctx *ctx, swmi_batch *b, const swmi_params *p
             pr.n_cells = outs[k].n_cells;
             if (outs[k].flags & SWMI_F_CELL_OVF) ovf.push_back(lo + k);
         }
-        b->raw_chunks.push_back(swmi_batch::RawChunk{raw_at, (size_t)used, lo, {}});
         lo = hi;
     }
 
@@ -1443,14 +1521,11 @@ extern "C" int swmi_batch_run(swmi_ctx *ctx, swmi_batch *b, const swmi_params *p
                 words += w2[hi2].dir_words;
                 hi2++;
             }
-            uint64_t used = 0;
-            const size_t raw_at2 = b->raw.size();
-            int rc = run_chunk(rs, w2, lo2, hi2, &exact, outs, b->raw, used);
+            int rc = run_chunk(rs, w2, lo2, hi2, &exact, outs);
             if (rc) return rc;
-            swmi_batch::RawChunk rc2{raw_at2, (size_t)used, lo2, {}};
+            swmi_batch::RawChunk &rc2 = b->raw_chunks.back();                              // (the launch's records, just appended)
             rc2.wpos.resize(hi2 - lo2);
             for (size_t k = 0; k < hi2 - lo2; k++) rc2.wpos[k] = (uint32_t)ovf[lo2 + k];   // chunk-local id -> position in `work`
-            b->raw_chunks.push_back(std::move(rc2));
             for (size_t k = 0; k < hi2 - lo2; k++) b->pairs[w2[lo2 + k].pair].n_cells = outs[k].n_cells;
             for (size_t k = 0; k < hi2 - lo2; k++)
                 if (outs[k].flags & SWMI_F_CELL_OVF)
@@ -1609,7 +1684,7 @@ static void materialise(swmi_batch *b, uint64_t pair, HostAln &a, uint64_t slot)
     char *sr = b->str_buf.data() + b->str_at[slot], *sq = sr + a.n_ops + 1;
     sr[a.n_ops] = 0; sq[a.n_ops] = 0;
     int64_t i = a.end_i, j = a.end_j;     // 1-based cell of the op being emitted (both >= 1 while ops remain)
-    const uint32_t *ops = b->ops.data() + a.ops_at;
+    const uint32_t *ops = a.rec;
     // Four ops (one byte of the packed stream) at a time: a table gives, for each of the 256 byte values, how far behind the
     // current cell every op reads its reference / read base (or that it writes '_'), so the four characters of each string do
     // not wait for each other's i, j -- the per-op loop below is one dependent chain per character.
@@ -1675,13 +1750,20 @@ extern "C" int swmi_pair_alignment(swmi_batch *b, uint64_t pair, uint64_t k,
         return SWMI_OK;
     }
     HostAln &a = b->alns[pr.first + k];
-    if (a.str_id < 0) materialise(b, pair, a, pr.first + k);
     if (begin) *begin = a.begin;
     if (end_i) *end_i = a.end_i;
     if (end_j) *end_j = a.end_j;
+    if (len) *len = a.n_ops;
+    if (b->rec_strings) {
+        // both strings were written by the traceback kernel right behind the record (swmi_emit.h): pointers only
+        const uint32_t *sr = a.rec + (a.n_ops + 15u) / 16u;
+        if (ref_aln) *ref_aln = (const char *)sr;
+        if (read_aln) *read_aln = (const char *)(sr + a.n_ops / 4u + 1u);
+        return SWMI_OK;
+    }
+    if (a.str_id < 0) materialise(b, pair, a, pr.first + k);
     if (ref_aln) *ref_aln = b->str_buf.data() + a.str_id;
     if (read_aln) *read_aln = b->str_buf.data() + a.str_id + a.n_ops + 1;
-    if (len) *len = a.n_ops;
     return SWMI_OK;
 }
 
@@ -1699,6 +1781,11 @@ extern "C" int swmi_batch_materialise_all(swmi_batch *b, uint64_t *n_alignments,
         if (pr.flags & SWMI_PAIR_DEGENERATE) { na += pr.n_cells; continue; }     // (0, "", "") each: nothing to build
         for (uint64_t k = 0; k < pr.count; k++) nc += 2ull * b->alns[pr.first + k].n_ops;
         na += pr.count;
+    }
+    if (b->rec_strings) {          // the kernels wrote every string: the index is all there was to do
+        if (n_alignments) *n_alignments = na;
+        if (n_chars) *n_chars = nc;
+        return SWMI_OK;
     }
     // every string has its own place in str_buf: pairs are built independently, by a few threads when there is enough to do
     // (streamed chunks re-read reference bytes through a cache that is not thread-safe: one thread there)
@@ -1839,7 +1926,7 @@ struct swmi_stream {
     std::mutex mu;
     std::condition_variable cv_free, cv_ready;
     bool closing = false;
-    int err = 0;
+    std::atomic<int> err{0};                   // (read by the workers and parsers outside `mu`)
     std::string err_msg;
     uint32_t next_id = 0;                      // chunk ids in reference order
     uint32_t in_flight = 0;
@@ -1853,7 +1940,7 @@ struct swmi_stream {
 
 static void stream_fail(swmi_stream *s, int rc, const std::string &msg) {
     std::lock_guard<std::mutex> g(s->mu);
-    if (!s->err) { s->err = rc; s->err_msg = msg; }
+    if (!s->err.load()) { s->err_msg = msg; s->err.store(rc); }
     s->cv_free.notify_all(); s->cv_ready.notify_all();
 }
 
@@ -1891,7 +1978,9 @@ static int stream_process(swmi_stream *s, swmi_stream::Slot &sl, StreamChunk *c)
     r->pairs = std::move(b->pairs);
     (void)settle_raw(b);
     r->raw = std::move(b->raw);
+    r->rtab = std::move(b->rtab);
     r->raw_chunks = std::move(b->raw_chunks);
+    r->rec_strings = b->rec_strings;
     r->indexed = false;
     r->ref_view_ready.assign(n_refs, 0);
     r->ref_sites.assign(n_refs, {});
@@ -1899,7 +1988,7 @@ static int stream_process(swmi_stream *s, swmi_stream::Slot &sl, StreamChunk *c)
     r->timing = b->timing;
     if (!c->recs.empty()) { r->src_map = s->map_p; r->src_recs = std::move(c->recs); }
     else r->ref_bytes = std::move(c->keep);
-    b->pairs.clear(); b->raw.clear(); b->raw_chunks.clear(); b->has_run = false;
+    b->pairs.clear(); b->raw.clear(); b->rtab.clear(); b->raw_chunks.clear(); b->has_run = false;
     std::lock_guard<std::mutex> g(s->mu);
     if (s->results.size() <= c->id) s->results.resize(c->id + 1, nullptr);
     s->results[c->id] = r.release();
@@ -1922,8 +2011,8 @@ static void stream_worker(swmi_stream *s, size_t slot) {
             c = s->ready.front();
             s->ready.pop_front();
         }
-        int rc = s->err ? s->err : stream_process(s, sl, c);
-        if (rc && !s->err) stream_fail(s, rc, swmi_last_error());
+        int rc = s->err.load() ? s->err.load() : stream_process(s, sl, c);
+        if (rc && !s->err.load()) stream_fail(s, rc, swmi_last_error());
         {
             std::lock_guard<std::mutex> g(s->mu);
             s->free_bufs.push_back(c->buf);
@@ -2018,7 +2107,7 @@ extern "C" int swmi_stream_push(swmi_stream *s, const uint8_t *ref_bytes, const 
         while (hi < n_refs && (hi == lo || ref_off[hi + 1] - ref_off[lo] <= s->chunk_bytes)) hi++;
         const uint64_t bytes = ref_off[hi] - ref_off[lo];
         PinnedBuf *pb = stream_take_buf(s, std::max<uint64_t>(bytes, 16));
-        if (!pb) return fail(s->err ? s->err : SWMI_ERR_NOMEM, "%s", s->err_msg.c_str());
+        if (!pb) return fail(s->err.load() ? s->err.load() : SWMI_ERR_NOMEM, "%s", s->err_msg.c_str());
         StreamChunk *c = new StreamChunk;
         c->buf = pb;
         c->off.resize(hi - lo + 1);
@@ -2063,8 +2152,7 @@ extern "C" int swmi_stream_push_file(swmi_stream *s, const char *path, const cha
         for (;;) {
             const uint32_t k = next.fetch_add(1);
             if (k >= n_seg || s->err) return;
-            // segments are parsed in order of their id, and a parser only takes a buffer once the segment before its own
-            // has one: with every buffer in use the oldest chunks are the ones being worked on, never starved by later ones
+            // (segments are taken in id order; the workers pop the lowest ready id, so later segments never starve earlier ones)
             const auto p0 = std::chrono::steady_clock::now();
             PinnedBuf *pb = stream_take_buf(s, std::max<uint64_t>(cut[k + 1] - cut[k], 16));
             if (!pb) return;

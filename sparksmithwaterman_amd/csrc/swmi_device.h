@@ -18,7 +18,8 @@
 //                     Every store instruction therefore writes 256 contiguous bytes.
 //   cells  uint2[]    per pair, up to cell_cap (i, j) coordinates of the tied maximum cells.
 //   out    PairOut[]  per pair score / count / flags.
-//   arena  uint32[]   variable-length alignment records appended by the traceback kernel.
+//   rec_tab AlnRec[]  one entry per alignment, in the order the traceback kernels reserved them;
+//   arena  uint32[]   the alignments' variable-length payloads (packed ops, the two aligned strings).
 #pragma once
 #include <stdint.h>
 
@@ -83,16 +84,21 @@ struct PairOut {
     uint64_t n_cells;     // number of tied maximum cells (m*n when degenerate)
 };
 
-// header of one alignment record in the arena (followed by ceil(n_ops/16) dwords of 2-bit ops,
-// op t of the traceback (first = the max cell) at bits 2*(t%16) of dword t/16)
+// One alignment = one entry of the RECORD TABLE (dense, 8 dwords each, in the order the records were reserved) + its payload
+// in the arena: ceil(n_ops/16) dwords of 2-bit ops (op t of the traceback, first = the max cell, at bits 2*(t%16) of dword
+// t/16) and -- when TraceArgs.raw is set -- the two aligned strings GetAlignment returns (SmithWaterman.java:418-431):
+// refAligned then readAligned, n_ops/4 + 1 dwords each (NUL-terminated, NUL-padded).  The table is what the host indexes: a
+// dense array reads at memory bandwidth, where headers scattered through the arena were one dependent cache miss per record
+// (0.11 ms per 1161 records of a pinned block the GPU had just written).
 struct AlnRec {
     uint32_t out_id;
     uint32_t rank;        // position of the alignment in OptAlignments order
     int32_t  begin;       // GetAlignment's `beginning` (SmithWaterman.java:378-383)
     int32_t  end_i, end_j;
     uint32_t n_ops;
+    uint32_t off_lo, off_hi;   // dword offset of the payload in the arena
 };
-#define SWMI_ALNREC_WORDS 6u
+#define SWMI_RECTAB_WORDS 8u
 
 struct ArenaHdr {
     unsigned long long used_words;   // bump pointer (may exceed capacity: records past it are dropped)
@@ -163,6 +169,12 @@ struct TraceArgs {
     uint4          *q_items;     // {pair index of the launch, i, j, 0}
     uint32_t        q_cap;
     uint32_t        pad4;
+    // the two aligned strings of every alignment, written behind its record (swmi_emit.h): the caller's bytes as uploaded
+    const uint8_t  *raw;         // null: records carry the 2-bit ops only and the host builds the strings
+    const uint64_t *raw_off;     // byte offsets into raw: n_refs + 1 for the references, then n_reads + 1 for the reads
+    uint32_t        raw_reads_at;   // index of the reads' first offset in raw_off (= n_refs + 1)
+    uint32_t        rec_tab_cap;    // entries the record table holds
+    AlnRec         *rec_tab;        // the record table (host-mapped with zero-copy results)
 };
 
 // extra arguments of sw_resident_pairs_kernel (kept out of TraceArgs: the traceback kernels are at their SGPR limit)
@@ -214,15 +226,16 @@ SWMI_HD static inline uint32_t swmi_rows_per_lane(uint32_t m) {
 }
 // dwords of per-pair workspace.  mode 0: the direction field; mode 1: lane-state checkpoints + one maximum per
 // checkpoint window; mode 2: lane-state checkpoints.
-SWMI_HD static inline uint64_t swmi_dir_words(uint32_t m, uint32_t n, uint32_t mode) {
+// tfused: the context lets sw_tfused_kernel take pairs (option "tfused" = 1): such a pair keeps its column checkpoints in the
+// same region, which must then hold them.
+SWMI_HD static inline uint64_t swmi_dir_words(uint32_t m, uint32_t n, uint32_t mode, bool tfused = false) {
     uint32_t R = swmi_rows_per_lane(m);
     uint64_t strips = ((uint64_t)m + 64u * R - 1u) / (64u * R);
     uint64_t wblocks = ((uint64_t)n + 63u + 15u) / 16u;   // T = n + 63 steps at most
     if (mode == 0) return strips * wblocks * R * 64u;
     uint64_t n_ck = (wblocks + SWMI_CK_BLOCKS - 1u) / SWMI_CK_BLOCKS;
     uint64_t words = strips * (n_ck * (R + 2u) * 64u + (mode == 1 ? ((n_ck + 63u) & ~(uint64_t)63u) : 0u));
-    // (a pair the transposed kernel may take keeps its column checkpoints in the same region)
-    if (mode == 1 && m <= 256u && n <= 64u * 40u && ((uint64_t)m + 64u) * 64u > words) words = ((uint64_t)m + 64u) * 64u;
+    if (tfused && mode == 1 && m <= 256u && n <= 64u * 40u && ((uint64_t)m + 64u) * 64u > words) words = ((uint64_t)m + 64u) * 64u;
     return words;
 }
 // int32 seam rows of a pair whose read spans several strips: one row of n+1 per strip

@@ -30,6 +30,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include "swmi_device.h"
+#include "swmi_emit.h"
 
 #define WAVE 64
 #ifndef SWMI_HELPER_SLEEP
@@ -1102,6 +1103,9 @@ __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDes
     const uint32_t ugdec = A.gap > 0 ? (uint32_t)A.gap : 0u;  // ... and one gap move
     (void)udec; (void)ugdec;                                  // (only the SWMI_WALK_DIAGONALS build of the walk uses them)
     const bool acgt = rd.acgt && qd.acgt && SWMI_SCORES_FIT(A);
+    // the caller's own bytes of the two sequences (for the aligned strings; loaded here, long before they are needed)
+    const uint8_t *__restrict__ raw_ref = A.raw ? A.raw + A.raw_off[pd.ref_id] : nullptr;
+    const uint8_t *__restrict__ raw_read = A.raw ? A.raw + A.raw_off[A.raw_reads_at + pd.read_id] : nullptr;
 
     // (s_setprio for the walker over the helpers sharing its SIMD: measured, no effect)
     uint32_t *lds_ops = lds;                                   // [A.lds_words]      one op per BYTE, staged per alignment
@@ -1390,32 +1394,42 @@ __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDes
             n_steps += n_ops;
             WAVE_SYNC();
 
-            // ---- append the record: header + ops packed 2 bits each (16 per dword) ----
+            // ---- the record: a table entry + the payload (ops packed 2 bits each, 16 per dword [+ the two aligned strings]) ----
             const uint32_t opw = (n_ops + 15u) / 16u;
-            const uint32_t words = SWMI_ALNREC_WORDS + opw;
-            unsigned long long off = 0;
-            if (lane == 0) {
-                off = atomicAdd(&A.hdr->used_words, (unsigned long long)words);
-            }
-            off = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(off >> 32)) << 32) |
-                  (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)off);
-            if (off + words <= A.arena_cap_words && n_ops <= 4u * A.lds_words) {
-                uint32_t *dst = A.arena + off;
-                if (lane == 0) {
-                    dst[0] = pd.out_id; dst[1] = crank; dst[2] = (uint32_t)begin;
-                    dst[3] = ci; dst[4] = cj; dst[5] = n_ops;
-                }
-                for (uint32_t w = lane; w < opw; w += WAVE) {
-                    uint32_t packed = 0;
+            const uint32_t words = swmi_payload_words(n_ops, A.raw != nullptr);
+            const SwmiReserve rsv = swmi_reserve_issue(A, lane, words, 1u);
+            // while the reservation is on its way: this lane's first dword of packed ops, and the last 256 characters of
+            // GetAlignment's two strings (SmithWaterman.java:418-431) from the caller's own bytes.  The walker's direction tile
+            // is free between two walks (its helpers wait for the next request) and serves as scratch.
+            const bool staged = n_ops <= 4u * A.lds_words;
+            auto pack16 = [&](uint32_t w) {
+                uint32_t packed = 0;
 #pragma unroll
-                    for (uint32_t c = 0; c < 4; ++c) {
-                        const uint32_t first = 16u * w + 4u * c;
-                        uint32_t x = first < n_ops ? lds_ops[4u * w + c] : 0u;
-                        if (first + 4u > n_ops && first < n_ops) x &= (1u << (8u * (n_ops - first))) - 1u;
-                        const uint32_t b8 = (x & 3u) | ((x >> 6) & 0xCu) | ((x >> 12) & 0x30u) | ((x >> 18) & 0xC0u);
-                        packed |= b8 << (8u * c);
-                    }
-                    dst[SWMI_ALNREC_WORDS + w] = packed;
+                for (uint32_t c = 0; c < 4; ++c) {
+                    const uint32_t first = 16u * w + 4u * c;
+                    uint32_t x = first < n_ops ? lds_ops[4u * w + c] : 0u;
+                    if (first + 4u > n_ops && first < n_ops) x &= (1u << (8u * (n_ops - first))) - 1u;
+                    const uint32_t b8 = (x & 3u) | ((x >> 6) & 0xCu) | ((x >> 12) & 0x30u) | ((x >> 18) & 0xC0u);
+                    packed |= b8 << (8u * c);
+                }
+                return packed;
+            };
+            const uint32_t packed0 = (staged && lane < opw) ? pack16(lane) : 0u;
+            SwmiStrings<SwmiOpsPerByte> strs(SwmiOpsPerByte{ops_b}, staged ? n_ops : 0u, ci, cj, raw_ref, raw_read, lane, lds_tile);
+            const uint32_t sw = strs.words(), ctop = strs.n_chunks();
+            uint32_t wr0 = 0, wq0 = 0;
+            if (A.raw && staged) strs.chunk(ctop - 1u, wr0, wq0);
+            unsigned long long off;
+            uint32_t rslot;
+            if (swmi_reserve_finish(A, rsv, words, 1u, off, rslot) && staged) {
+                uint32_t *dst = A.arena + off;
+                if (lane == 0) swmi_write_rec(A, rslot, pd.out_id, crank, begin, ci, cj, n_ops, off);
+                if (lane < opw) dst[lane] = packed0;
+                for (uint32_t w = lane + WAVE; w < opw; w += WAVE) dst[w] = pack16(w);
+                if (A.raw) {
+                    const uint32_t w = 64u * (ctop - 1u) + lane;
+                    if (w < sw) { dst[opw + w] = wr0; dst[opw + sw + w] = wq0; }
+                    strs.store_from(dst + opw, ctop - 1u);
                 }
             } else if (lane == 0) {
                 atomicOr(&A.out[pd.out_id].flags, SWMI_F_ARENA_OVF);
@@ -1852,7 +1866,7 @@ sw_walk_items_kernel(const TraceArgs A) {
 //      copy their records out.  Periodic references give every pair a handful of alignments: they cost one walk, not five.
 // No checkpoints, no HBM workspace.  The host orders a pair's records by cell (SWMI_RANK_BY_CELL).
 // LDS per wavefront (dwords): field [wblocks*R*64] | window maxima [n_ck] | cells [2*cell_cap] | ops [64*ops_words] |
-//                             reference codes [(n+3)/4+1] | read codes [(m+3)/4+1]
+//                             reference codes [(n+3)/4+1] | read codes [(m+3)/4+1] | string scratch [128]
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t wave_scan_add_u32(uint32_t v) {          // inclusive prefix sum over the 64 lanes (DPP)
 #define SWMI_DPP_ADD(ctrl, rmask, bmask)                                                     \
@@ -1883,6 +1897,7 @@ __device__ __forceinline__ void resident_pair(const TraceArgs &A, const Resident
     uint32_t *opsb = reinterpret_cast<uint32_t *>(cells + X.res_cell_cap);
     uint32_t *refc = opsb + WAVE * X.res_ops_words;
     uint32_t *readc = refc + (n + 3u) / 4u + 1u;
+    uint32_t *scratch = readc + (m + 3u) / 4u + 1u;                         // [SWMI_EMIT_SCRATCH_WORDS] 256 characters of both strings
     for (uint32_t w = lane; w < (n + 3u) / 4u; w += WAVE) refc[w] = refw[w];
     for (uint32_t w = lane; w < (m + 3u) / 4u; w += WAVE) readc[w] = readw[w];
     const uint4 *__restrict__ refq = reinterpret_cast<const uint4 *>(refw);
@@ -2006,22 +2021,34 @@ __device__ __forceinline__ void resident_pair(const TraceArgs &A, const Resident
         }
         if ((nops & 15u) != 0u && nops <= max_ops) my_ops[nops >> 4] = cur;
         WAVE_SYNC();
-        // records: header + packed ops, contiguous for the whole wave
+        // records: table entries + payloads (packed ops [+ strings]), contiguous for the whole wave
         const uint32_t opw = (nops + 15u) / 16u;
-        const uint32_t words = mine ? SWMI_ALNREC_WORDS + opw : 0u;
+        const uint32_t words = mine ? swmi_payload_words(nops, A.raw != nullptr) : 0u;
         const uint32_t incl = wave_scan_add_u32(words);
         const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        unsigned long long off = 0;
-        if (lane == 0) off = atomicAdd(&A.hdr->used_words, (unsigned long long)total);
-        off = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(off >> 32)) << 32) |
-              (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)off);
+        const uint32_t nhere = ncell - base < WAVE ? ncell - base : WAVE;
+        unsigned long long off;
+        uint32_t rslot;
+        const bool fits = swmi_reserve(A, lane, total, nhere, off, rslot);
         const bool too_long = BALLOT(mine && nops > max_ops) != 0ull;
-        if (off + total <= A.arena_cap_words && !too_long) {
+        if (fits && !too_long) {
             if (mine) {
                 uint32_t *dst = A.arena + off + (incl - words);
-                dst[0] = pd.out_id; dst[1] = SWMI_RANK_BY_CELL; dst[2] = (uint32_t)begin;
-                dst[3] = c0.x; dst[4] = c0.y; dst[5] = nops;
-                for (uint32_t w = 0; w < opw; ++w) dst[SWMI_ALNREC_WORDS + w] = my_ops[w];
+                swmi_write_rec(A, rslot + lane, pd.out_id, SWMI_RANK_BY_CELL, begin, c0.x, c0.y, nops, off + (incl - words));
+                for (uint32_t w = 0; w < opw; ++w) dst[w] = my_ops[w];
+            }
+            if (A.raw) {
+                // the strings (SmithWaterman.java:418-431): one alignment after the other, the whole wavefront on each
+                const uint8_t *__restrict__ raw_ref = A.raw + A.raw_off[pd.ref_id];
+                const uint8_t *__restrict__ raw_read = A.raw + A.raw_off[A.raw_reads_at + pd.read_id];
+                for (uint32_t a = 0; a < nhere; ++a) {
+                    const uint32_t na = (uint32_t)__builtin_amdgcn_readlane((int)nops, (int)a);
+                    const uint32_t at = (uint32_t)__builtin_amdgcn_readlane((int)(incl - words), (int)a);
+                    const uint32_t ai = (uint32_t)__builtin_amdgcn_readlane((int)c0.x, (int)a);
+                    const uint32_t aj = (uint32_t)__builtin_amdgcn_readlane((int)c0.y, (int)a);
+                    swmi_emit_strings(A.arena + off + at + (na + 15u) / 16u, SwmiOpsPacked{opsb + a * X.res_ops_words},
+                                      na, ai, aj, raw_ref, raw_read, lane, scratch);
+                }
             }
         } else if (lane == 0) {
             atomicOr(&A.out[pd.out_id].flags, SWMI_F_ARENA_OVF);

@@ -35,6 +35,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include "swmi_device.h"
+#include "swmi_emit.h"
 
 #define WAVE 64
 #define TF_WAVES 4                       // wavefronts of a workgroup that sweep a pair each
@@ -82,6 +83,7 @@ __device__ __forceinline__ int tf_profile(uint32_t code, bool inside, int match,
 struct TfPair {
     uint32_t n, m, B, L;             // reference / read length, columns per lane of the sweep, lanes that hold columns
     const uint8_t *ref_b, *read_b;   // LDS copies of the byte images
+    const uint8_t *raw_ref, *raw_read;   // the caller's own bytes (for the aligned strings), or null
     uint32_t *ck;                    // column checkpoints [step][lane]
     int match, mismatch;
     uint32_t g;                      // -gap > 0
@@ -265,7 +267,8 @@ struct TfSlot {                      // one per sweeper = per pair of the workgr
     uint32_t n, m, out_id, pmax;
     uint32_t ck_lo, ck_hi;           // the pair's column checkpoints
     uint32_t tasks_total, tasks_done, cells;
-    uint32_t pad[7];
+    uint32_t ref_id, read_id;        // (for the caller's own bytes: the aligned strings)
+    uint32_t pad[5];
 };
 struct TfQueue {
     uint32_t n, taken, lock, pad;
@@ -352,7 +355,7 @@ __device__ __forceinline__ bool tf_walk(const TraceArgs &A, const TFusedArgs &X,
                                         int foreign, const uint32_t me, const uint32_t lane, const TfRegion &R) {
     const uint32_t umat = (uint32_t)A.match, umis = (uint32_t)A.mismatch, ugap = (uint32_t)A.gap;
     uint8_t *stage_b = reinterpret_cast<uint8_t *>(R.stage);
-    const uint32_t stage_cap = 4u * X.stage_words;
+    const uint32_t stage_cap = 4u * (X.stage_words - SWMI_EMIT_SCRATCH_WORDS);   // (the tail of the staging area: scratch of swmi_emit_strings)
     uint32_t i = ci, j = cj, score = (uint32_t)pmax, nops = 0;
     int begin = 0;
     bool bad = false, moved = false;
@@ -407,14 +410,13 @@ __device__ __forceinline__ bool tf_walk(const TraceArgs &A, const TFusedArgs &X,
     }
     if (foreign >= 0 && lane == 0) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); tf_lds_add(&sh->tile_users[foreign], 0xFFFFFFFFu); }
     WAVE_SYNC();
-    // the record: header + the staged ops (one per byte) packed 16 per dword
-    const uint32_t opw = (nops + 15u) / 16u, words = SWMI_ALNREC_WORDS + opw;
-    unsigned long long off = 0;
-    if (lane == 0) off = atomicAdd(&A.hdr->used_words, (unsigned long long)words);
-    off = ((unsigned long long)tf_uni((uint32_t)(off >> 32)) << 32) | tf_uni((uint32_t)off);
-    if (off + words <= A.arena_cap_words && !bad && nops <= stage_cap) {
+    // the record: a table entry + the payload -- the staged ops (one per byte) packed 16 per dword [+ the two strings]
+    const uint32_t opw = (nops + 15u) / 16u, words = swmi_payload_words(nops, A.raw != nullptr);
+    unsigned long long off;
+    uint32_t rslot;
+    if (swmi_reserve(A, lane, words, 1u, off, rslot) && !bad && nops <= stage_cap) {
         uint32_t *dst = A.arena + off;
-        if (lane == 0) { dst[0] = out_id; dst[1] = SWMI_RANK_BY_CELL; dst[2] = (uint32_t)begin; dst[3] = ci; dst[4] = cj; dst[5] = nops; }
+        if (lane == 0) swmi_write_rec(A, rslot, out_id, SWMI_RANK_BY_CELL, begin, ci, cj, nops, off);
         for (uint32_t w = lane; w < opw; w += WAVE) {
             uint32_t v = 0;
 #pragma unroll
@@ -424,8 +426,11 @@ __device__ __forceinline__ bool tf_walk(const TraceArgs &A, const TFusedArgs &X,
             }
             const uint32_t rem = nops - 16u * w;
             if (rem < 16u) v &= (1u << (2u * rem)) - 1u;
-            dst[SWMI_ALNREC_WORDS + w] = v;
+            dst[w] = v;
         }
+        if (A.raw)                                                        // the two strings GetAlignment returns (SmithWaterman.java:418-431)
+            swmi_emit_strings(dst + opw, SwmiOpsPerByte{stage_b}, nops, ci, cj, P.raw_ref, P.raw_read, lane,
+                              R.stage + (X.stage_words - SWMI_EMIT_SCRATCH_WORDS));
     } else if (lane == 0) {
         atomicOr(&A.out[out_id].flags, SWMI_F_ARENA_OVF);
         if (A.ovf_host) *A.ovf_host = 1u;
@@ -544,6 +549,8 @@ __device__ __forceinline__ void tf_workgroup(const TraceArgs &A, const TFusedArg
         P.ck = const_cast<uint32_t *>(A.dir) + pd.dir_off;
         P.match = A.match; P.mismatch = A.mismatch;
         P.g = g;
+        P.raw_ref = A.raw ? A.raw + A.raw_off[pd.ref_id] : nullptr;
+        P.raw_read = A.raw ? A.raw + A.raw_off[A.raw_reads_at + pd.read_id] : nullptr;
         int lane_max = 0;
         const int pmax = tf_sweep_dispatch(P, lane, lane_max);
         if (A.dbg) tk_sweep = __builtin_amdgcn_s_memtime() - tk_start - tk_pro;
@@ -570,6 +577,7 @@ __device__ __forceinline__ void tf_workgroup(const TraceArgs &A, const TFusedArg
             if (lane == 0) {
                 PairOut po; po.score = pmax; po.flags = 0u; po.n_cells = 0; A.out[pd.out_id] = po;
                 myslot->n = n; myslot->m = m; myslot->out_id = pd.out_id; myslot->pmax = (uint32_t)pmax;
+                myslot->ref_id = pd.ref_id; myslot->read_id = pd.read_id;
                 const unsigned long long cka = (unsigned long long)(uintptr_t)P.ck;
                 myslot->ck_lo = (uint32_t)cka; myslot->ck_hi = (uint32_t)(cka >> 32);
                 // the rightmost block is this wavefront's own next piece of work; the others go to the queue
@@ -628,6 +636,8 @@ __device__ __forceinline__ void tf_workgroup(const TraceArgs &A, const TFusedArg
         P.ck = reinterpret_cast<uint32_t *>((uintptr_t)(((unsigned long long)tf_uni(slot->ck_hi) << 32) | tf_uni(slot->ck_lo)));
         P.match = A.match; P.mismatch = A.mismatch;
         P.g = g;
+        P.raw_ref = A.raw ? A.raw + A.raw_off[tf_uni(slot->ref_id)] : nullptr;
+        P.raw_read = A.raw ? A.raw + A.raw_off[A.raw_reads_at + tf_uni(slot->read_id)] : nullptr;
     };
     // everybody: block tasks first, then walk items, until every pair of the workgroup is through.  A helper lists cells
     // without handing any out (allow_push false): nobody ever reads a helper's tile, so a helper never waits.

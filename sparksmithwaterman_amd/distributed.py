@@ -22,6 +22,21 @@ def shard_references(refs, rank, world):
     return refs[lo:hi], lo
 
 
+def shard_by_length(lengths, rank, world):
+    """Length-balanced shard of ONE reference set: the references sorted by length, longest first, are
+    dealt to the ranks in a snake (0..w-1, w-1..0, ...), so every rank gets the same number of references (+-1) and
+    nearly the same number of DP cells whatever the length distribution (NCBI-shaped sets are log-normal: a contiguous
+    split by count can leave one rank with the few 100 kbp records).  Returns this rank's GLOBAL reference ids, ascending
+    (the order the references had in the set, which is what the result file keeps, Distribution.java:359)."""
+    import numpy as np
+    n = np.asarray(lengths, dtype=np.int64)
+    order = np.argsort(-n, kind="stable")              # longest first, ties in set order
+    pos = np.arange(order.size)
+    lap, col = pos // world, pos % world
+    owner = np.where(lap % 2 == 0, col, world - 1 - col)
+    return np.sort(order[owner == rank])
+
+
 def _decode(g, cap):
     """rows {local max, uncapped count, ids...} of every rank -> (global max, winners or None when a winning rank has
     more ids than fit the fixed payload, the largest such count)"""
@@ -168,24 +183,32 @@ class MaxReducer:
 
 def global_top_k(local_totals, global_ids, k, device=None, group=None):
     """Top-k (total, id) over all ranks: each rank contributes its local top-k (k x 16 B), merged everywhere.
-    Ties are broken by ascending reference id so every rank returns the same list."""
+    Ties are broken by ascending reference id so every rank returns the same list.
+
+    Both selections are ONE torch.topk over a composite int64 key, total * 2^32 + (2^32 - 1 - id): totals are Java
+    ints (Distribution.java:424) and ids fit 32 bits, so the key orders by total descending, then id ascending."""
+    import numpy as np
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    t = torch.as_tensor(list(local_totals), dtype=torch.int64)
-    ids = torch.as_tensor(list(global_ids), dtype=torch.int64)
-    order = sorted(range(t.numel()), key=lambda i: (-int(t[i]), int(ids[i])))[:k]
-    payload = torch.full((k, 2), -(1 << 62), dtype=torch.int64, device=device)
-    for r, i in enumerate(order):
-        payload[r, 0] = t[i]
-        payload[r, 1] = ids[i]
+    t = torch.from_numpy(np.ascontiguousarray(np.asarray(local_totals, dtype=np.int64)))
+    ids = torch.from_numpy(np.ascontiguousarray(np.asarray(global_ids, dtype=np.int64)))
+    if ids.numel() and (int(ids.min()) < 0 or int(ids.max()) > 0xFFFFFFFF):
+        raise ValueError("reference ids must fit 32 bits")
+    key = (t << 32) + (0xFFFFFFFF - ids)
+    sentinel = -(1 << 63)                              # (below every real key but {total -2^31, id 2^32 - 1})
+    payload = torch.full((k,), sentinel, dtype=torch.int64)
+    kk = min(k, key.numel())
+    if kk:
+        payload[:kk] = torch.topk(key, kk).values
+    if device is not None:
+        payload = payload.to(device)
     if world > 1:
         gathered = [torch.empty_like(payload) for _ in range(world)]
         dist.all_gather(gathered, payload, group=group)
+        allk = torch.cat(gathered).cpu()
     else:
-        gathered = [payload]
-    rows = []
-    for g in gathered:
-        for tot, i in g.cpu().tolist():
-            if tot > -(1 << 62):
-                rows.append((int(tot), int(i)))
-    rows.sort(key=lambda x: (-x[0], x[1]))
-    return rows[:k]
+        allk = payload.cpu()
+    allk = allk[allk > sentinel]
+    best = torch.topk(allk, min(k, allk.numel())).values if allk.numel() else allk
+    tot = best >> 32                                   # (arithmetic shift: negative totals survive)
+    rid = 0xFFFFFFFF - (best & 0xFFFFFFFF)
+    return [(int(a), int(b)) for a, b in zip(tot.tolist(), rid.tolist())]

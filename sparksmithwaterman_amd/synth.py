@@ -17,9 +17,10 @@ _ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
 class SplitMix64:
     def __init__(self, seed):
         self.state = np.uint64(seed)
+        self._buf = np.empty(0, dtype=np.uint64)      # outputs generated ahead for one-at-a-time callers (same stream)
+        self._at = 0
 
-    def next(self, n=1):
-        """next n outputs as a uint64 array"""
+    def _gen(self, n):
         with np.errstate(over="ignore"):
             k = np.arange(1, n + 1, dtype=np.uint64)
             z = self.state + k * _GAMMA
@@ -27,6 +28,30 @@ class SplitMix64:
             z = (z ^ (z >> np.uint64(30))) * _M1
             z = (z ^ (z >> np.uint64(27))) * _M2
             return z ^ (z >> np.uint64(31))
+
+    def next(self, n=1):
+        """next n outputs as a uint64 array.  Single draws are served from a block generated ahead -- the outputs and
+        their order are those of the plain generator, only the batching differs (noisy_read draws ~1.1 numbers per base)."""
+        left = self._buf.size - self._at
+        if n == 1:
+            if left == 0:
+                self._buf, self._at, left = self._gen(4096), 0, 4096
+                self._lst = self._buf.tolist()
+            self._at += 1
+            return self._buf[self._at - 1:self._at]
+        if left == 0:
+            return self._gen(n)
+        head = self._buf[self._at:self._at + min(n, left)]
+        self._at += head.size
+        return head if head.size == n else np.concatenate([head, self._gen(n - head.size)])
+
+    def take(self):
+        """one output as a Python int (the same stream as next(1))"""
+        if self._at == self._buf.size:
+            self.next(1)
+            return self._lst[self._at - 1]
+        self._at += 1
+        return self._lst[self._at - 1]
 
     def bases(self, n, chunk=1 << 24):
         """n bases; drawn in chunks (same stream, same result) so that 10^9 bases do not need 10^10 bytes of temporaries"""
@@ -51,22 +76,23 @@ def noisy_read(rng, src, m, sub=0.05, indel=0.01):
     """
     out = bytearray()
     p = 0
+    acgt = b"ACGT"
     while len(out) < m and p < len(src):
-        u = float(rng.uniform(1)[0])
+        u = (rng.take() >> 11) * (1.0 / (1 << 53))
         c = src[p]
         if u < sub:
-            k = b"ACGT".index(bytes([c]))
-            out.append(b"ACGT"[(k + 1 + int(rng.next(1)[0] >> np.uint64(62)) % 3) % 4])
+            k = acgt.index(c)
+            out.append(acgt[(k + 1 + (rng.take() >> 62) % 3) % 4])
             p += 1
         elif u < sub + indel / 2:
             p += 1
         elif u < sub + indel:
-            out.append(b"ACGT"[int(rng.next(1)[0] >> np.uint64(62))])
+            out.append(acgt[rng.take() >> 62])
         else:
             out.append(c)
             p += 1
     while len(out) < m:
-        out.append(b"ACGT"[int(rng.next(1)[0] >> np.uint64(62))])
+        out.append(acgt[rng.take() >> 62])
     return bytes(out)
 
 

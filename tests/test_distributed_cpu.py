@@ -84,3 +84,23 @@ def test_shard_bounds_cover_everything():
 def test_single_process_reduce_without_init():
     assert swd.global_max_with_ties([1, 9, 9], [10, 11, 12]) == (9, [11, 12])
     assert swd.global_top_k([1, 9, 9], [10, 11, 12], 2) == [(9, 11), (9, 12)]
+
+
+def test_shard_by_length_is_a_balanced_partition():
+    import numpy as np
+    rng = np.random.default_rng(7)
+    lens = np.clip(np.rint(np.exp(rng.normal(7.38, 0.77, 5003))), 50, 100000).astype(np.int64)
+    for w in (1, 2, 3, 8):
+        parts = [swd.shard_by_length(lens, r, w) for r in range(w)]
+        assert sorted(np.concatenate(parts).tolist()) == list(range(lens.size))
+        assert all((np.diff(p) > 0).all() for p in parts)                       # ascending global ids
+        assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+        cells = [int(lens[p].sum()) for p in parts]
+        assert max(cells) - min(cells) <= int(lens.max())                        # within one (longest) reference of each other
+    assert swd.shard_by_length([], 0, 2).size == 0
+
+
+def test_top_k_orders_by_total_then_id_and_keeps_negative_totals():
+    assert swd.global_top_k([5, -7, 5, 0, -1], [40, 41, 12, 3, 9], 4) == [(5, 12), (5, 40), (0, 3), (-1, 9)]
+    assert swd.global_top_k([], [], 3) == []
+    assert swd.global_top_k([2**31 - 1, -2**31], [0, 2**32 - 2], 5) == [(2**31 - 1, 0), (-2**31, 2**32 - 2)]

@@ -20,9 +20,11 @@ READ_20 = "ACTGACTGACTGACTGACTG"   # EngineerData.java:29
 
 
 @pytest.fixture(scope="module", params=[(1, 1, 0, 0, 0), (2, 1, 0, 0, 0), (0, 1, 0, 0, 0), (1, 0, 0, 0, 0), (-1, 1, -1, -1, -1), (1, 1, 1, 0, 0),
-                                        (1, 0, 1, 0, 0), (1, 1, 0, 1, 0), (1, 0, -1, 1, 0), (1, 1, 0, 0, 1), (1, 0, -1, -1, 1)],
+                                        (1, 0, 1, 0, 0), (1, 1, 0, 1, 0), (1, 0, -1, 1, 0), (1, 1, 0, 0, 1), (1, 0, -1, -1, 1),
+                                        (-1, 1, -1, -1, -1, 0)],
                 ids=["mode1-winmax", "mode2-events", "mode0-field", "mode1-d2h-copy", "automatic", "mode1-split-traceback",
-                     "mode1-split-d2h-copy", "mode1-resident", "mode1-resident-d2h-copy", "mode1-tfused", "mode1-tfused-d2h-copy"])
+                     "mode1-split-d2h-copy", "mode1-resident", "mode1-resident-d2h-copy", "mode1-tfused", "mode1-tfused-d2h-copy",
+                     "automatic-host-strings"])
 def ctx(request):
     """Every kernel pipeline (include/swmi.h, swmi_set_option "mode"), results written straight to pinned host
     memory or fetched by a copy, the mode-1 traceback with one workgroup per pair or split per window / alignment
@@ -35,6 +37,8 @@ def ctx(request):
     c.set_option("tb_split", request.param[2])
     c.set_option("resident", request.param[3])
     c.set_option("tfused", request.param[4])
+    # the two aligned strings are written by the traceback kernels (the default); 0: the host builds them from the 2-bit ops
+    c.set_option("device_strings", request.param[5] if len(request.param) > 5 else 1)
     c.test_resident = request.param[3]
     c.test_tfused = request.param[4]
     yield c

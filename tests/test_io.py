@@ -173,6 +173,29 @@ def test_stream_from_memory_matches_one_batch(tmp_path):
 
 
 @pytest.mark.gpu
+def test_stream_views_keep_their_stream_alive_and_die_with_it():
+    """`ctx.stream(reads).push(refs).finish().chunks()` leaves no name for the Stream -- the views must keep it
+    alive (swmi_stream_close frees every result batch); after an explicit close a view raises instead of reading freed memory."""
+    import gc
+    from sparksmithwaterman_amd import synth
+    from oracle import sw_oracle as orc
+    refs, reads = synth.config_ncbi(40, read_len=150, seed=5)
+    ctx = sw.Context(0)
+    chunks = ctx.stream(reads, slots=2, chunk_bytes=64 << 10).push(refs).finish().chunks()
+    gc.collect()
+    first, c = chunks[-1]
+    assert c.score(0) == orc.opt_alignments((refs[first], reads[0]))[0]
+    assert c.alignments(0) == orc.opt_alignments((refs[first], reads[0]))[1]
+    st = c._owner
+    st.close()
+    with pytest.raises(sw.SwmiError):
+        c.score(0)
+    with pytest.raises(sw.SwmiError):
+        chunks[0][1].alignments(0)
+    ctx.close()
+
+
+@pytest.mark.gpu
 def test_stream_from_fasta_file_100k_references(tmp_path):
     """configs[2] shape through the streamed path: a FASTA file of 100,000 NCBI-shaped references (log-normal
     lengths, median 1,609 bp), parsed segment-wise into pinned memory, canonicalised on the GPU, aligned chunk by chunk on
