@@ -86,6 +86,15 @@ def test_kats(ctx, kats):
         b.free()
 
 
+def test_map_ref_goldens(ctx, map_ref_goldens):
+    """EngineerData-shaped MapRef goldens (tests/golden/engineerdata_small.json): total and the stably sorted match sites"""
+    for g in map_ref_goldens:
+        b = ctx.upload([g["ref"]], g["reads"]).run(sw.make_params(g["scores"], tuple("aid-"), g["tie_mode"]))
+        assert b.ref_total(0) == g["total"], g["name"]
+        assert [[x[0], x[1][0], x[1][1]] for x in b.ref_match_sites(0)] == g["match_sites"], g["name"]
+        b.free()
+
+
 def test_mirror_classes_match_reference_call_shapes(ctx):
     score, alns = sw.SmithWaterman.OptAlignments(ctx).call(["ACGT", "CG"], [5, -3, -4], ["a", "i", "d", "-"])
     assert (score, alns) == (10, [(2, ("CG", "CG"))])

@@ -109,3 +109,25 @@ def test_latin1_uppercase_rule():
     assert orc.opt_alignments(("\xff", "\xdf"))[0] == 0
     assert opy.opt_alignments(("\xe9", "\xc9"))[0] == 5
     assert opy.opt_alignments(("\xf7", "\xd7"))[0] == 0
+
+
+def test_engineerdata_goldens_are_what_the_generator_writes():
+    """tests/golden/engineerdata_small.json is data produced by tools/gen_engineerdata_golden.py (C oracle, required equal
+    from the Python twin): the committed file must be exactly what the generator builds today."""
+    import importlib.util
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gen_engineerdata_golden", os.path.join(root, "tools", "gen_engineerdata_golden.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    with open(os.path.join(root, "tests", "golden", "engineerdata_small.json")) as f:
+        assert json.load(f) == gen.build()
+
+
+def test_map_ref_goldens_both_oracles(map_ref_goldens):
+    for g in map_ref_goldens:
+        t, (_, sites) = orc.map_ref((">gi|ref0", g["ref"]), g["reads"], g["scores"], b"aid-", g["tie_mode"])
+        assert (t, _norm(sites)) == (g["total"], g["match_sites"]), g["name"]
+        t2, (_, s2) = opy.map_ref((">gi|ref0", g["ref"]), g["reads"], tuple(g["scores"]), ("a", "i", "d", "-"), strict=bool(g["tie_mode"]))
+        assert (t2, _norm(s2)) == (g["total"], g["match_sites"]), g["name"]
