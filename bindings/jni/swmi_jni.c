@@ -128,3 +128,60 @@ JNIEXPORT jobjectArray JNICALL Java_sw_GpuSmithWaterman_nativeRefSite(JNIEnv *en
     (*env)->SetObjectArrayElement(env, out, 1, qa);
     return out;
 }
+
+/* {number of match sites, bytes of all their strings} of the references refLo .. refHi-1 */
+JNIEXPORT jlongArray JNICALL Java_sw_GpuSmithWaterman_nativeRefSitesSizes(JNIEnv *env, jclass cls, jlong batch, jint refLo, jint refHi) {
+    char err[640];
+    int64_t sz[2] = {0, 0};
+    jlong jsz[2];
+    jlongArray out;
+    (void)cls;
+    if (swmi_shim_ref_sites_sizes((swmi_batch *)(intptr_t)batch, refLo, refHi, sz, err, sizeof err) != SWMI_OK) { throw_msg(env, err); return NULL; }
+    out = (*env)->NewLongArray(env, 2);
+    if (!out) return NULL;
+    jsz[0] = (jlong)sz[0]; jsz[1] = (jlong)sz[1];
+    (*env)->SetLongArrayRegion(env, out, 0, 2, jsz);
+    return out;
+}
+
+/* MapRef's output of a whole range of references into the caller's arrays: ONE call per partition (swmi_shim.h) */
+JNIEXPORT void JNICALL Java_sw_GpuSmithWaterman_nativeRefSitesPacked(
+        JNIEnv *env, jclass cls, jlong batch, jint refLo, jint refHi, jintArray totals, jlongArray degenerate, jlongArray siteFirst,
+        jintArray begins, jintArray lens, jlongArray strOff, jbyteArray blob) {
+    char err[640];
+    jint *t, *bg, *ln;
+    jlong *dg, *sf, *so;
+    jbyte *bl;
+    int rc = SWMI_ERR_NOMEM;
+    (void)cls;
+    if (!totals || !degenerate || !siteFirst || !begins || !lens || !strOff || !blob) { throw_msg(env, "nativeRefSitesPacked: null array argument"); return; }
+    t = (*env)->GetIntArrayElements(env, totals, NULL);
+    dg = (*env)->GetLongArrayElements(env, degenerate, NULL);
+    sf = (*env)->GetLongArrayElements(env, siteFirst, NULL);
+    bg = (*env)->GetIntArrayElements(env, begins, NULL);
+    ln = (*env)->GetIntArrayElements(env, lens, NULL);
+    so = (*env)->GetLongArrayElements(env, strOff, NULL);
+    bl = (*env)->GetByteArrayElements(env, blob, NULL);
+    if (t && dg && sf && bg && ln && so && bl) {
+        jsize ns = (*env)->GetArrayLength(env, begins);
+        if ((*env)->GetArrayLength(env, lens) < ns) ns = (*env)->GetArrayLength(env, lens);
+        if ((*env)->GetArrayLength(env, strOff) < ns) ns = (*env)->GetArrayLength(env, strOff);
+        rc = swmi_shim_ref_sites_packed((swmi_batch *)(intptr_t)batch, refLo, refHi,
+                                        (int32_t *)t, (int64_t)(*env)->GetArrayLength(env, totals),
+                                        (int64_t *)dg, (int64_t)(*env)->GetArrayLength(env, degenerate),
+                                        (int64_t *)sf, (int64_t)(*env)->GetArrayLength(env, siteFirst),
+                                        (int32_t *)bg, (int32_t *)ln, (int64_t *)so, (int64_t)ns,
+                                        (signed char *)bl, (int64_t)(*env)->GetArrayLength(env, blob), err, sizeof err);
+    } else {
+        snprintf(err, sizeof err, "nativeRefSitesPacked: out of memory pinning the output arrays");
+    }
+    /* mode 0: copy back (if the VM handed out copies) and release */
+    if (t) (*env)->ReleaseIntArrayElements(env, totals, t, 0);
+    if (dg) (*env)->ReleaseLongArrayElements(env, degenerate, dg, 0);
+    if (sf) (*env)->ReleaseLongArrayElements(env, siteFirst, sf, 0);
+    if (bg) (*env)->ReleaseIntArrayElements(env, begins, bg, 0);
+    if (ln) (*env)->ReleaseIntArrayElements(env, lens, ln, 0);
+    if (so) (*env)->ReleaseLongArrayElements(env, strOff, so, 0);
+    if (bl) (*env)->ReleaseByteArrayElements(env, blob, bl, 0);
+    if (rc != SWMI_OK) throw_msg(env, err);
+}

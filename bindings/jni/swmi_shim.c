@@ -70,3 +70,36 @@ int swmi_shim_ref_site(swmi_batch *b, int32_t ref, int64_t k, int32_t *begin, co
     rc = swmi_ref_match_site(b, (uint32_t)ref, (uint64_t)k, begin, ref_aln, read_aln, len);
     return rc == SWMI_OK ? rc : shim_fail(rc, err, err_len, "swmi_ref_match_site", swmi_last_error());
 }
+
+int swmi_shim_ref_sites_sizes(swmi_batch *b, int32_t ref_lo, int32_t ref_hi, int64_t sizes[2], char *err, size_t err_len) {
+    uint64_t ns = 0, nb = 0;
+    int rc;
+    if (ref_lo < 0 || ref_hi < ref_lo) return shim_fail(SWMI_ERR_RANGE, err, err_len, "nativeRefSitesSizes", "bad reference range");
+    if (!sizes) return shim_fail(SWMI_ERR_INVALID, err, err_len, "nativeRefSitesSizes", "sizes is null");
+    rc = swmi_ref_sites_packed(b, (uint32_t)ref_lo, (uint32_t)ref_hi, NULL, NULL, NULL, NULL, NULL, NULL, 0, NULL, 0, &ns, &nb);
+    if (rc != SWMI_OK) return shim_fail(rc, err, err_len, "swmi_ref_sites_packed", swmi_last_error());
+    sizes[0] = (int64_t)ns; sizes[1] = (int64_t)nb;
+    return SWMI_OK;
+}
+
+int swmi_shim_ref_sites_packed(swmi_batch *b, int32_t ref_lo, int32_t ref_hi,
+                               int32_t *totals, int64_t n_totals, int64_t *degenerate, int64_t n_degenerate,
+                               int64_t *site_first, int64_t n_site_first,
+                               int32_t *begins, int32_t *lens, int64_t *str_off, int64_t n_sites_cap,
+                               signed char *blob, int64_t blob_cap, char *err, size_t err_len) {
+    uint64_t ns = 0, nb = 0;
+    int64_t n;
+    int rc;
+    if (ref_lo < 0 || ref_hi < ref_lo) return shim_fail(SWMI_ERR_RANGE, err, err_len, "nativeRefSitesPacked", "bad reference range");
+    n = (int64_t)ref_hi - ref_lo;
+    if (!totals || !degenerate || !site_first || !begins || !lens || !str_off || (!blob && blob_cap > 0))
+        return shim_fail(SWMI_ERR_INVALID, err, err_len, "nativeRefSitesPacked", "null array argument");
+    if (n_totals < n || n_degenerate < n || n_site_first < n + 1 || n_sites_cap < 0 || blob_cap < 0)
+        return shim_fail(SWMI_ERR_INVALID, err, err_len, "nativeRefSitesPacked", "an output array is shorter than the reference range needs");
+    /* jint / jlong and the C-ABI's unsigned types have the same sizes; counts were checked non-negative */
+    rc = swmi_ref_sites_packed(b, (uint32_t)ref_lo, (uint32_t)ref_hi, totals, (uint64_t *)(void *)degenerate,
+                               (uint64_t *)(void *)site_first, begins, (uint32_t *)(void *)lens, (uint64_t *)(void *)str_off,
+                               (uint64_t)n_sites_cap, (uint8_t *)(void *)blob, (uint64_t)blob_cap, &ns, &nb);
+    if (rc != SWMI_OK) return shim_fail(rc, err, err_len, "swmi_ref_sites_packed", swmi_last_error());
+    return SWMI_OK;
+}

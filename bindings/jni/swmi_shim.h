@@ -32,6 +32,17 @@ int swmi_shim_ref_site_count(swmi_batch *b, int32_t ref, int64_t *n, char *err, 
 int swmi_shim_ref_site(swmi_batch *b, int32_t ref, int64_t k, int32_t *begin, const char **ref_aln, const char **read_aln,
                        uint32_t *len, char *err, size_t err_len);
 
+/* nativeRefSitesSizes / nativeRefSitesPacked: MapRef's output of the references ref_lo .. ref_hi-1 in ONE call
+ * (swmi_ref_sites_packed, include/swmi.h).  The Java side asks for the sizes, allocates its int[] / long[] / byte[] once per
+ * partition, and builds every String from a slice of one byte[] -- instead of three JNI calls and two array allocations per
+ * match site.  `sizes` receives {number of sites, bytes of all strings}.  Lengths are checked against the arrays' lengths. */
+int swmi_shim_ref_sites_sizes(swmi_batch *b, int32_t ref_lo, int32_t ref_hi, int64_t sizes[2], char *err, size_t err_len);
+int swmi_shim_ref_sites_packed(swmi_batch *b, int32_t ref_lo, int32_t ref_hi,
+                               int32_t *totals, int64_t n_totals, int64_t *degenerate, int64_t n_degenerate,
+                               int64_t *site_first, int64_t n_site_first,
+                               int32_t *begins, int32_t *lens, int64_t *str_off, int64_t n_sites_cap,
+                               signed char *blob, int64_t blob_cap, char *err, size_t err_len);
+
 #ifdef __cplusplus
 }
 #endif

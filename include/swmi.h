@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define SWMI_ABI_VERSION 2
+#define SWMI_ABI_VERSION 3
 
 typedef enum swmi_status {
     SWMI_OK               =  0,
@@ -79,7 +79,10 @@ void        swmi_default_params(swmi_params *p);
  * fast path (pairs with more are re-run on the GPU with an exact-size list);
  * max_workspace_bytes: cap on the per-batch workspace arena (larger batches are run in
  * chunks); profiling != 0 brackets every kernel with HIP events; zero_copy (default 1): kernels
- * write results straight into pinned host memory instead of a D2H copy; mode selects the kernel
+ * write results straight into pinned host memory instead of a D2H copy; device_strings (default 1): the traceback kernels
+ * write both aligned strings of every alignment behind its packed ops (from the caller's bytes as uploaded), so the
+ * alignment accessors hand out pointers; 0: records carry the 2-bit ops only and the host builds a string when it is asked
+ * for (smaller result stream, e.g. when only a few of many alignments will ever be read); mode selects the kernel
  * pipeline -- results are identical in all of them:
  *   1 (default)  the sweep computes scores only, leaves lane-state checkpoints and ONE maximum per
  *                32-step window; the traceback re-sweeps the windows holding the pair's maximum to list
@@ -173,6 +176,19 @@ int      swmi_ref_totals(const swmi_batch *b, int32_t *totals, uint32_t n);
 int      swmi_ref_n_match_sites(swmi_batch *b, uint32_t ref, uint64_t *n);
 int      swmi_ref_match_site(swmi_batch *b, uint32_t ref, uint64_t k, int32_t *begin,
                              const char **ref_aln, const char **read_aln, uint32_t *len);
+
+/* MapRef's output for the references ref_lo .. ref_hi-1 in ONE call -- what a per-partition binding hands back
+ * (Distribution.java:419-433) instead of three calls per match site.  Per reference r (index r - ref_lo): totals[] (:424),
+ * degenerate[] = how many leading (0, "", "") sites it has (pairs whose maximum is 0 contribute m*n each,
+ * SmithWaterman.java:154,182-185; they are counted, not listed) and site_first[] .. site_first[+1] = its real match sites in
+ * MapRef order (stable sort by begin, :428) within begins[] / lens[] / str_off[]: site s has refAligned at blob + str_off[s]
+ * and readAligned at blob + str_off[s] + lens[s], lens[s] bytes each, no terminators.  site_first has ref_hi - ref_lo + 1
+ * entries.  *n_sites / *blob_bytes always receive the sizes needed: call with begins = NULL to ask for them, then with
+ * buffers of at least that capacity (too small: SWMI_ERR_RANGE).  totals / degenerate / site_first may be NULL. */
+int      swmi_ref_sites_packed(swmi_batch *b, uint32_t ref_lo, uint32_t ref_hi,
+                               int32_t *totals, uint64_t *degenerate, uint64_t *site_first,
+                               int32_t *begins, uint32_t *lens, uint64_t *str_off, uint64_t sites_cap,
+                               uint8_t *blob, uint64_t blob_cap, uint64_t *n_sites, uint64_t *blob_bytes);
 
 /* ---- one-shot path: what a per-partition JNI call binds -------------------------- */
 /* upload + run; results are read with the accessors above; free with swmi_batch_free. */

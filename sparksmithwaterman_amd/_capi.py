@@ -72,6 +72,8 @@ SYMBOLS = [
     ("swmi_ref_n_match_sites", C.c_int, [_P, C.c_uint32, _u64p]),
     ("swmi_ref_match_site", C.c_int, [_P, C.c_uint32, C.c_uint64, C.POINTER(C.c_int32), C.POINTER(C.c_char_p),
                                       C.POINTER(C.c_char_p), C.POINTER(C.c_uint32)]),
+    ("swmi_ref_sites_packed", C.c_int, [_P, C.c_uint32, C.c_uint32, C.POINTER(C.c_int32), _u64p, _u64p, C.POINTER(C.c_int32),
+                                        C.POINTER(C.c_uint32), _u64p, C.c_uint64, C.c_void_p, C.c_uint64, _u64p, _u64p]),
     ("swmi_stream_open", C.c_int, [_P, C.POINTER(Params), C.c_char_p, _u64p, C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(_P)]),
     ("swmi_stream_push", C.c_int, [_P, C.c_char_p, _u64p, C.c_uint32]),
     ("swmi_stream_push_file", C.c_int, [_P, C.c_char_p, C.c_char_p, C.c_uint32]),

@@ -76,7 +76,8 @@ class Batch:
         return object.__getattribute__(self, name)
 
     _NEEDS_HANDLE = frozenset(("run", "run_async", "wait", "timing", "pipeline_mode", "score", "n_alignments", "alignment",
-                               "alignments", "pair_results", "materialise_all", "ref_total", "ref_totals", "ref_match_sites"))
+                               "alignments", "pair_results", "materialise_all", "ref_total", "ref_totals", "ref_match_sites",
+                               "ref_sites_packed"))
 
     def __init__(self, ctx, refs, reads):
         self._ctx = ctx
@@ -176,6 +177,37 @@ class Batch:
         for k in range(n.value):
             check(self._lib.swmi_ref_match_site(self._h, ref, k, C.byref(b), C.byref(r), C.byref(q), C.byref(ln)))
             out.append((b.value, (r.value.decode("latin-1"), q.value.decode("latin-1"))))
+        return out
+
+    def ref_sites_packed(self, ref_lo=0, ref_hi=None):
+        """MapRef's output of references ref_lo .. ref_hi-1 in two native calls (sizes, then data): a list of
+        (total, n_degenerate, [(begin, (refAligned, readAligned)), ...]) -- what swmi_ref_sites_packed hands a JNI binding."""
+        import numpy as np
+        ref_hi = self.n_refs if ref_hi is None else ref_hi
+        n = ref_hi - ref_lo
+        ns, nb = C.c_uint64(), C.c_uint64()
+        check(self._lib.swmi_ref_sites_packed(self._h, ref_lo, ref_hi, None, None, None, None, None, None, 0, None, 0,
+                                              C.byref(ns), C.byref(nb)))
+        totals = np.empty(max(n, 1), dtype=np.int32)
+        deg = np.empty(max(n, 1), dtype=np.uint64)
+        first = np.empty(n + 1, dtype=np.uint64)
+        begins = np.empty(max(ns.value, 1), dtype=np.int32)
+        lens = np.empty(max(ns.value, 1), dtype=np.uint32)
+        off = np.empty(max(ns.value, 1), dtype=np.uint64)
+        blob = np.empty(max(nb.value, 1), dtype=np.uint8)
+        P = C.POINTER
+        check(self._lib.swmi_ref_sites_packed(
+            self._h, ref_lo, ref_hi, totals.ctypes.data_as(P(C.c_int32)), deg.ctypes.data_as(P(C.c_uint64)),
+            first.ctypes.data_as(P(C.c_uint64)), begins.ctypes.data_as(P(C.c_int32)), lens.ctypes.data_as(P(C.c_uint32)),
+            off.ctypes.data_as(P(C.c_uint64)), ns.value, blob.ctypes.data_as(C.c_void_p), nb.value, C.byref(ns), C.byref(nb)))
+        raw = blob.tobytes()
+        out = []
+        for r in range(n):
+            sites = []
+            for s in range(int(first[r]), int(first[r + 1])):
+                o, ln = int(off[s]), int(lens[s])
+                sites.append((int(begins[s]), (raw[o:o + ln].decode("latin-1"), raw[o + ln:o + 2 * ln].decode("latin-1"))))
+            out.append((int(totals[r]), int(deg[r]), sites))
         return out
 
     def free(self):

@@ -1156,9 +1156,10 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
                 HIP_TRY(hipMemcpy(&hdr_copy, ta.hdr, sizeof hdr_copy, hipMemcpyDeviceToHost));
                 hdr = &hdr_copy;
             }
-        } else {
-            overflow = hdr->used_words > arena_cap || hdr->n_records > tab_cap;
         }
+        const uint64_t hdr_words = zc && !overflow ? 0 : hdr->reserved & SWMI_HDR_WORD_MASK;     // (zero-copy: only read after an overflow)
+        const uint64_t hdr_recs = zc && !overflow ? 0 : hdr->reserved >> SWMI_HDR_WORD_BITS;
+        if (!zc) overflow = hdr_words > arena_cap || hdr_recs > tab_cap;
         if (overflow) {            // records were dropped: grow to the exact need and redo the traceback
             if (zc) {
                 saved_outs.resize(np * sizeof(PairOut));
@@ -1172,8 +1173,12 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
                 // the split traceback counts a pair's cells by atomics and flags list overflows itself: start both over
                 if (split && !(so.flags & SWMI_F_DEGENERATE)) { so.n_cells = 0; so.flags &= ~SWMI_F_CELL_OVF; }
             }
-            arena_cap = std::max<uint64_t>(arena_cap, hdr->used_words + 1024);
-            tab_cap = std::max<uint64_t>(tab_cap, hdr->n_records + 64);
+            arena_cap = std::max<uint64_t>(arena_cap, hdr_words + 1024);
+            tab_cap = std::max<uint64_t>(tab_cap, hdr_recs + 64);
+            // (the kernels reserve payload and table entry with one 64-bit counter: 36 bits of dwords, 28 bits of records)
+            if (arena_cap >= SWMI_HDR_WORD_MASK || tab_cap >= (1ull << (64u - SWMI_HDR_WORD_BITS)) - 1ull)
+                return fail(SWMI_ERR_UNSUPPORTED, "one launch would hold %llu alignment records in %llu arena dwords: lower max_workspace_bytes so that the batch runs in smaller launches",
+                            (unsigned long long)tab_cap, (unsigned long long)arena_cap);
             ctx->arena_words_per_pair = std::max<uint64_t>(ctx->arena_words_per_pair, arena_cap / np + 1);
             ctx->recs_per_pair_x16 = std::max<uint64_t>(ctx->recs_per_pair_x16, tab_cap * 16 / np + 1);
             continue;
@@ -1186,7 +1191,7 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
             for (auto &o : outs)
                 if (!(o.flags & (SWMI_F_DEGENERATE | SWMI_F_CELL_OVF))) n_rec += o.n_cells;
         } else {
-            n_rec = hdr->n_records;
+            n_rec = hdr_recs;
         }
         if (n_rec > tab_cap) return fail(SWMI_ERR_HIP, "more records than the table holds");
         const AlnRec *tab = (const AlnRec *)(h + t_off);
@@ -1195,10 +1200,10 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
             if (n_rec > copy_recs)
                 HIP_TRY(hipMemcpy((uint8_t *)b->h_result.p + t_off + copy_recs * sizeof(AlnRec), res + t_off + copy_recs * sizeof(AlnRec),
                                   (n_rec - copy_recs) * sizeof(AlnRec), hipMemcpyDeviceToHost));
-            if (hdr->used_words > copy_words)
+            if (hdr_words > copy_words)
                 HIP_TRY(hipMemcpy((uint8_t *)b->h_result.p + a_off + copy_words * 4, res + a_off + copy_words * 4,
-                                  (hdr->used_words - copy_words) * 4, hipMemcpyDeviceToHost));
-            ctx->arena_copy_wpp = hdr->used_words * 5 / (4 * np) + 2;
+                                  (hdr_words - copy_words) * 4, hipMemcpyDeviceToHost));
+            ctx->arena_copy_wpp = hdr_words * 5 / (4 * np) + 2;
             ctx->recs_per_pair_x16 = std::max<uint64_t>(ctx->recs_per_pair_x16, n_rec * 20 / np + 1);
         }
         if (!rs.keep) return SWMI_OK;
@@ -1890,6 +1895,58 @@ extern "C" int swmi_ref_match_site(swmi_batch *b, uint32_t ref, uint64_t k, int3
     if (k - deg >= b->ref_sites[ref].size()) return fail(SWMI_ERR_RANGE, "match site %llu out of range", (unsigned long long)k);
     const SiteRef &s = b->ref_sites[ref][k - deg];
     return swmi_pair_alignment(b, s.pair, s.k, begin, nullptr, nullptr, ref_aln, read_aln, len);
+}
+
+// MapRef's output for a range of references in ONE call: what a per-partition binding (JNI, one call per Spark partition)
+// hands back instead of three calls and two array allocations per match site (Distribution.java:419-433).
+extern "C" int swmi_ref_sites_packed(swmi_batch *b, uint32_t ref_lo, uint32_t ref_hi,
+                                     int32_t *totals, uint64_t *degenerate, uint64_t *site_first,
+                                     int32_t *begins, uint32_t *lens, uint64_t *str_off, uint64_t sites_cap,
+                                     uint8_t *blob, uint64_t blob_cap, uint64_t *n_sites, uint64_t *blob_bytes) {
+    if (!b) return fail(SWMI_ERR_INVALID, "batch is null");
+    if (!b->has_run) return fail(SWMI_ERR_INVALID, "batch has no results (run it first)");
+    if (ref_lo > ref_hi || ref_hi > b->n_refs) return fail(SWMI_ERR_RANGE, "reference range [%u, %u) out of range", ref_lo, ref_hi);
+    int rc = ensure_indexed(b);
+    if (rc) return rc;
+    // pass 1: counts (always), so that a caller may ask for the sizes first (begins == NULL or capacities too small)
+    uint64_t ns = 0, nb = 0;
+    for (uint32_t r = ref_lo; r < ref_hi; r++) {
+        build_ref_view(b, r);
+        for (const SiteRef &sr : b->ref_sites[r]) nb += 2ull * b->alns[b->pairs[sr.pair].first + sr.k].n_ops;
+        ns += b->ref_sites[r].size();
+    }
+    if (n_sites) *n_sites = ns;
+    if (blob_bytes) *blob_bytes = nb;
+    const bool fill = begins && lens && str_off && (blob || nb == 0) && sites_cap >= ns && blob_cap >= nb;
+    uint64_t s_at = 0, c_at = 0;
+    for (uint32_t r = ref_lo; r < ref_hi; r++) {
+        if (totals) { int32_t t = 0; (void)swmi_ref_total(b, r, &t); totals[r - ref_lo] = t; }
+        if (degenerate) degenerate[r - ref_lo] = b->ref_degenerate[r];           // leading (0, "", "") sites, not listed one by one
+        if (site_first) site_first[r - ref_lo] = s_at;
+        if (fill)
+            for (const SiteRef &sr : b->ref_sites[r]) {
+                const PairRes &pr = b->pairs[sr.pair];
+                HostAln &a = b->alns[pr.first + sr.k];
+                const char *ra, *qa;
+                if (b->rec_strings) {
+                    const uint32_t *w = a.rec + (a.n_ops + 15u) / 16u;
+                    ra = (const char *)w; qa = (const char *)(w + a.n_ops / 4u + 1u);
+                } else {
+                    if (a.str_id < 0) materialise(b, sr.pair, a, pr.first + sr.k);
+                    ra = b->str_buf.data() + a.str_id; qa = ra + a.n_ops + 1;
+                }
+                begins[s_at] = a.begin; lens[s_at] = a.n_ops; str_off[s_at] = c_at;
+                memcpy(blob + c_at, ra, a.n_ops);
+                memcpy(blob + c_at + a.n_ops, qa, a.n_ops);
+                c_at += 2ull * a.n_ops;
+                s_at++;
+            }
+        else s_at += b->ref_sites[r].size();
+    }
+    if (site_first) site_first[ref_hi - ref_lo] = s_at;
+    if (!fill && begins) return fail(SWMI_ERR_RANGE, "%llu sites / %llu string bytes do not fit the buffers (%llu / %llu)",
+                                     (unsigned long long)ns, (unsigned long long)nb, (unsigned long long)sites_cap, (unsigned long long)blob_cap);
+    return SWMI_OK;
 }
 
 

@@ -100,10 +100,16 @@ struct AlnRec {
 };
 #define SWMI_RECTAB_WORDS 8u
 
+// ONE 64-bit counter reserves both an alignment's payload and its table entry: the low 36 bits count arena dwords (they may
+// exceed the capacity: what does not fit is dropped and the host re-runs with the size the counter then shows), the high 28
+// bits count records.  One atomic per alignment instead of two: device-scope atomics of every XCD on one line queue up, and
+// two per record made the traceback launch 10 us longer (profiles/r03/ab_one_atomic.txt).
 struct ArenaHdr {
-    unsigned long long used_words;   // bump pointer (may exceed capacity: records past it are dropped)
-    unsigned long long n_records;
+    unsigned long long reserved;     // n_records << 36 | used_words
+    unsigned long long pad;
 };
+#define SWMI_HDR_WORD_BITS 36u
+#define SWMI_HDR_WORD_MASK ((1ull << SWMI_HDR_WORD_BITS) - 1ull)
 
 struct FillArgs {
     const uint32_t *seqw;

@@ -36,28 +36,24 @@ SWMI_HD static inline uint32_t swmi_payload_words(uint32_t n_ops, bool strings) 
     return (n_ops + 15u) / 16u + (strings ? 2u * swmi_str_words(n_ops) : 0u);
 }
 
-// Lane 0 reserves `words` dwords of arena and `n_rec` table entries.  Two halves, so that the round trip of the two atomics
-// (device scope, ~1-2 us) overlaps what the wavefront can prepare without knowing where its record goes (packing the ops,
+// Lane 0 reserves `words` dwords of arena and `n_rec` table entries with ONE atomic (swmi_device.h: ArenaHdr).  Two halves,
+// so that its round trip (device scope, ~1-2 us) overlaps what the wavefront can prepare without knowing where its record goes (packing the ops,
 // the characters of the strings): swmi_reserve_issue returns the pending values, swmi_reserve_finish makes them wave-uniform
 // {payload offset, first table slot}.  false: something did not fit -- the caller raises SWMI_F_ARENA_OVF and the host re-runs
 // with the sizes the header then holds.
-struct SwmiReserve { unsigned long long o, s; };
+struct SwmiReserve { unsigned long long v; };
 __device__ __forceinline__ SwmiReserve swmi_reserve_issue(const TraceArgs &A, const uint32_t lane, const uint32_t words, const uint32_t n_rec) {
-    SwmiReserve r{0ull, 0ull};
-    if (lane == 0) {
-        r.o = atomicAdd(&A.hdr->used_words, (unsigned long long)words);
-        r.s = atomicAdd(&A.hdr->n_records, (unsigned long long)n_rec);
-    }
+    SwmiReserve r{0ull};
+    if (lane == 0) r.v = atomicAdd(&A.hdr->reserved, ((unsigned long long)n_rec << SWMI_HDR_WORD_BITS) | (unsigned long long)words);
     return r;
 }
 __device__ __forceinline__ bool swmi_reserve_finish(const TraceArgs &A, const SwmiReserve r, const uint32_t words, const uint32_t n_rec,
                                                     unsigned long long &off, uint32_t &slot) {
-    off = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(r.o >> 32)) << 32) |
-          (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)r.o);
-    const unsigned long long s1 = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(r.s >> 32)) << 32) |
-                                  (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)r.s);
-    slot = (uint32_t)s1;
-    return off + words <= A.arena_cap_words && s1 + n_rec <= (unsigned long long)A.rec_tab_cap;
+    const unsigned long long v = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(r.v >> 32)) << 32) |
+                                 (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)r.v);
+    off = v & SWMI_HDR_WORD_MASK;
+    slot = (uint32_t)(v >> SWMI_HDR_WORD_BITS);
+    return off + words <= A.arena_cap_words && (unsigned long long)slot + n_rec <= (unsigned long long)A.rec_tab_cap;
 }
 __device__ __forceinline__ bool swmi_reserve(const TraceArgs &A, const uint32_t lane, const uint32_t words, const uint32_t n_rec,
                                              unsigned long long &off, uint32_t &slot) {

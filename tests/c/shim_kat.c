@@ -42,6 +42,22 @@ int main(int argc, char **argv) {
     }
     printf("\n");
     if (swmi_shim_ref_site(b, 0, n, NULL, NULL, NULL, NULL, err, sizeof err) != SWMI_ERR_RANGE) { printf("ERROR range\n"); return 8; }
+    /* the same sites through the bulk accessor (one call per partition): a second output line in the same format */
+    {
+        int64_t sizes[2] = {0, 0}, deg[1], first[2], off[64];
+        int32_t tot[1], begins[64], lens[64];
+        signed char blob[1024];
+        if (swmi_shim_ref_sites_sizes(b, 0, 1, sizes, err, sizeof err) != SWMI_OK) { printf("ERROR %s\n", err); return 9; }
+        if (sizes[0] != n || sizes[0] > 64 || sizes[1] > (int64_t)sizeof blob) { printf("ERROR sizes %ld %ld\n", (long)sizes[0], (long)sizes[1]); return 9; }
+        /* arrays too short for the range, then a blob too small for the strings */
+        if (swmi_shim_ref_sites_packed(b, 0, 1, tot, 0, deg, 1, first, 2, begins, lens, off, 64, blob, (int64_t)sizeof blob, err, sizeof err) != SWMI_ERR_INVALID) { printf("ERROR short totals accepted\n"); return 9; }
+        if (sizes[1] > 0 && swmi_shim_ref_sites_packed(b, 0, 1, tot, 1, deg, 1, first, 2, begins, lens, off, 64, blob, sizes[1] - 1, err, sizeof err) != SWMI_ERR_RANGE) { printf("ERROR short blob accepted\n"); return 9; }
+        if (swmi_shim_ref_sites_packed(b, 0, 1, tot, 1, deg, 1, first, 2, begins, lens, off, 64, blob, (int64_t)sizeof blob, err, sizeof err) != SWMI_OK) { printf("ERROR %s\n", err); return 9; }
+        printf("%d %ld", (int)tot[0], (long)(deg[0] + first[1] - first[0]));
+        for (k = first[0]; k < first[1]; k++)
+            printf(" %d:%.*s/%.*s", (int)begins[k], (int)lens[k], (const char *)blob + off[k], (int)lens[k], (const char *)blob + off[k] + lens[k]);
+        printf("\n");
+    }
     swmi_batch_free(ctx, b);
     swmi_destroy(ctx);
     return 0;

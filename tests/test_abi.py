@@ -29,7 +29,7 @@ def test_header_symbols_all_bound_and_exported():
 
 def test_abi_version_and_default_params():
     lib = _capi.load()
-    assert lib.swmi_abi_version() == 2
+    assert lib.swmi_abi_version() == 3
     p = _capi.Params()
     lib.swmi_default_params(p)
     assert (p.match, p.mismatch, p.gap, p.tie_mode, p.types) == (5, -3, -4, 0, b"aid-")

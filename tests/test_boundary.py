@@ -45,10 +45,38 @@ def test_shim_sequence_matches_kat3(tmp_path, kats):
     exe = _build_shim(tmp_path)
     for arg, name in (("serial", "KAT-3-serial"), ("strict", "KAT-3-strict")):
         k = next(x for x in kats if x["name"] == name)
-        out = subprocess.run([str(exe), arg], capture_output=True, text=True, check=True).stdout.split()
+        lines = subprocess.run([str(exe), arg], capture_output=True, text=True, check=True).stdout.splitlines()
         want = k.get("map_ref_sorted", k["alignments"])
-        assert out[0] == str(k["score"]) and out[1] == str(len(want))
-        assert out[2:] == ["%d:%s/%s" % (b, r, q) for b, r, q in want]
+        # line 1: the per-site call sequence; line 2: the same sites through the bulk accessor (swmi_ref_sites_packed)
+        assert len(lines) == 2
+        for out in (ln.split() for ln in lines):
+            assert out[0] == str(k["score"]) and out[1] == str(len(want))
+            assert out[2:] == ["%d:%s/%s" % (b, r, q) for b, r, q in want]
+
+
+@pytest.mark.gpu
+def test_ref_sites_packed_is_map_ref_of_a_whole_partition():
+    """swmi_ref_sites_packed (what GpuSmithWaterman.MapPartition binds): totals, degenerate-site counts and every real match
+    site of a range of references, equal to the per-site accessors and to the oracle's MapRef (Distribution.java:403-436)."""
+    from oracle import sw_oracle as orc
+    refs = ["CCTGGGTCCTGCCTCGCATCTGACCAGGGCAGG" * 3, "ACGTTTGACCAacgtGGAC", "GGGG", "acgtACGTTGCAtgca" * 4, ""]
+    reads = ["CATCTGACCAGGGCAGGCCTGG", "TTTT", "ACGTTGCA", "GGAC"]
+    for zero_copy, strings in ((1, 1), (0, 1), (1, 0)):
+        ctx = sw.Context(0)
+        ctx.set_option("zero_copy", zero_copy)
+        ctx.set_option("device_strings", strings)
+        b = ctx.upload(refs, reads).run()
+        packed = b.ref_sites_packed()
+        assert len(packed) == len(refs)
+        for r, (total, n_deg, sites) in enumerate(packed):
+            wt, (_, ws) = orc.map_ref((">gi|r%d" % r, refs[r]), reads)
+            assert total == wt == b.ref_total(r)
+            assert [(0, ("", ""))] * n_deg + sites == ws == b.ref_match_sites(r)
+        assert b.ref_sites_packed(1, 3) == packed[1:3] and b.ref_sites_packed(2, 2) == []
+        with pytest.raises(sw.SwmiError):
+            b.ref_sites_packed(3, 9)
+        b.free()
+        ctx.close()
 
 
 @pytest.mark.gpu
