@@ -41,9 +41,15 @@ def alg_bytes(m, n):
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--n-refs", type=int, default=1000)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 50; 2 with --scaling strong)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps (default 5; 1 with --scaling strong)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak (default): configs[1], every rank its own 1,000-reference shard.  strong: configs[3], ONE set of --n-refs "
+                         "NCBI-shaped references x --n-reads reads sharded by length over the ranks, then the max/top-K reduce")
+    ap.add_argument("--n-refs", type=int, default=None, help="references (default 1000; 100000 with --scaling strong)")
+    ap.add_argument("--n-reads", type=int, default=1000, help="--scaling strong: reads (BASELINE.json configs[3] names 10000)")
+    ap.add_argument("--chunk-kb", type=int, default=512, help="--scaling strong: KiB of reference bases per streamed chunk")
+    ap.add_argument("--top-k", type=int, default=8)
     ap.add_argument("--ref-len", type=int, default=2000)
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -52,7 +58,15 @@ def parse_args():
     ap.add_argument("--tfused", type=int, default=None, help="transposed fused kernel (include/swmi.h): -1 automatic, 0 never, 1 every pair that qualifies")
     ap.add_argument("--mode", type=int, default=None, help="kernel pipeline (include/swmi.h): 1 default, 2 event-tracked maxima, 0 HBM direction field")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="any swmi_set_option knob, e.g. device_strings=0 (A/B runs)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    strong = args.scaling == "strong"
+    if args.steps is None:
+        args.steps = 2 if strong else 50
+    if args.warmup is None:
+        args.warmup = 1 if strong else 5
+    if args.n_refs is None:
+        args.n_refs = 100000 if strong else 1000
+    return args
 
 
 def free_port():
@@ -146,6 +160,12 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29541")
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     dev = torch.device("cpu") if (one_gpu and world > 1) else torch.device("cuda", local_rank)
+    if args.scaling == "strong":
+        strong_scaling(args, world, rank, local_rank, one_gpu, dev)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     # ---- synthetic inputs: shard `rank` of a world*n_refs reference set, the read of shard 0 --------------
     refs0, reads = synth.config_1k(args.n_refs, args.ref_len, args.read_len, seed=1)
@@ -343,6 +363,143 @@ def main():
         dist.barrier()
     if world > 1 or rehearse_rccl:
         dist.destroy_process_group()
+
+
+def strong_scaling(args, world, rank, local_rank, one_gpu, dev):
+    """BASELINE.json configs[3]: ONE reference set (NCBI-shaped, --n-refs) x --n-reads reads, the references sharded by length
+    over the ranks (distributed.shard_by_length), every rank streaming its shard through its GPU in chunks of --chunk-kb KiB
+    of references (each chunk = its references x all reads, full path: sweep + tied maxima + traceback + both strings of every
+    alignment written to host memory), then the driver's reduce over RCCL: max total with ties (Distribution.java:341-353,
+    600-613) + top-K, and the winners aligned once more into results that are kept (a chunk's records are dropped once its
+    totals are taken, like the reference's driver drops every non-winner's alignments).  A step = all of that once."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import sparksmithwaterman_amd as sw
+    from sparksmithwaterman_amd import synth
+    from sparksmithwaterman_amd import distributed as swd
+
+    g0 = time.perf_counter()
+    refs, reads = synth.config_multi_read(args.n_refs, args.n_reads, seed=3)       # (every rank the same set: deterministic)
+    gen_s = time.perf_counter() - g0
+    lengths = np.fromiter((len(r) for r in refs), dtype=np.int64, count=len(refs))
+    local_ids = swd.shard_by_length(lengths, rank, world)
+    mine = [refs[int(i)] for i in local_ids]
+    read_lens, read_cnt = np.unique([len(q) for q in reads], return_counts=True)
+    cells_rank = int(lengths[local_ids].sum()) * int(sum(len(q) for q in reads))
+    cells_all = int(lengths.sum()) * int(sum(len(q) for q in reads))
+    bytes_rank = sum(int(c) * alg_bytes(int(mq), int(n)) for n in lengths[local_ids] for mq, c in zip(read_lens, read_cnt))
+
+    ctx = sw.Context(local_rank)
+    ctx.set_option("profiling", 1)
+    ctx.set_option("stream_keep_records", 0)
+    for kv in args.opt:
+        name, _, value = kv.partition("=")
+        ctx.set_option(name, int(value))
+    params = sw.make_params()
+    rdev = None if (one_gpu or world == 1) else dev
+    mine_ids = set(int(x) for x in local_ids)
+    last = {}
+
+    def step():
+        st = ctx.stream(reads, params, slots=3, chunk_bytes=args.chunk_kb << 10)
+        try:
+            t0 = time.perf_counter()
+            st.push(mine).finish()
+            totals = st.totals().copy()
+            stats = st.stats()
+            t1 = time.perf_counter()
+            best, winners = swd.global_max_with_ties(totals, local_ids, device=rdev)
+            top = swd.global_top_k(totals, local_ids, args.top_k, device=rdev)
+            t2 = time.perf_counter()
+            # the winners this rank owns, aligned again into results that stay (MapRef's output for them)
+            own = [w for w in winners if w in mine_ids][:64]
+            sites = 0
+            if own:
+                wb = ctx.upload([refs[w] for w in own], reads).run(params)
+                sites = sum(len(s_) + d_ for _, d_, s_ in wb.ref_sites_packed())
+                wb.free()
+            t3 = time.perf_counter()
+        finally:
+            st.close()
+        last.update(totals=totals, best=best, winners=winners, top=top, sweep_ms=stats.gpu_sweep_ms, tb_ms=stats.gpu_traceback_ms,
+                    chunks=stats.chunks, align_s=t1 - t0, reduce_s=t2 - t1, winners_s=t3 - t2, winner_sites=sites)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    sweep_ms = tb_ms = align_s = reduce_s = winners_s = 0.0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        sweep_ms += last["sweep_ms"]; tb_ms += last["tb_ms"]
+        align_s += last["align_s"]; reduce_s += last["reduce_s"]; winners_s += last["winners_s"]
+    sync()
+    elapsed = time.perf_counter() - t0
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+
+    # the reduce on its own (blocking exchanges of this shard's totals), outside the timed region
+    for _ in range(2):
+        swd.global_max_with_ties(last["totals"], local_ids, device=rdev)
+    sync()
+    r0 = time.perf_counter()
+    for _ in range(10):
+        swd.global_max_with_ties(last["totals"], local_ids, device=rdev)
+        swd.global_top_k(last["totals"], local_ids, args.top_k, device=rdev)
+    reduce_ms = (time.perf_counter() - r0) / 10 * 1e3
+
+    if rank == 0:
+        sweep_s = sweep_ms / args.steps * 1e-3
+        achieved = bytes_rank / sweep_s / 1e9 if sweep_s > 0 else 0.0
+        out = {
+            "metric": "GCUPS", "value": round(cells_all * args.steps / elapsed / 1e9, 3), "unit": "GCUPS (1e9 DP cell updates/s, full path)",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "alignments_per_s": round(len(refs) * len(reads) * args.steps / elapsed, 1),
+            "reduce_ms": round(reduce_ms, 4),
+            "config": {"workload": "configs[3]: %d reads x 150 bp vs ONE set of %d NCBI-shaped references (median 1,609 bp), sharded by length over "
+                                   "%d rank(s), streamed in chunks of %d KiB of references; scores 5/-3/-4; full path for every pair (sweep + tied "
+                                   "maxima + traceback + both strings of every alignment to host memory), totals -> max-with-ties + top-%d over %s, "
+                                   "winners aligned again into kept results" % (len(reads), len(refs), world, args.chunk_kb, args.top_k,
+                                                                            ("gloo (one-GPU rehearsal)" if one_gpu else "RCCL") if world > 1 else "one rank"),
+                       "pairs": len(refs) * len(reads), "pairs_rank0": len(mine) * len(reads), "cells": cells_all, "cells_rank0": cells_rank,
+                       "parallelism": "references sharded by length over %d rank(s); no data-path collective" % world},
+            "rank0": {"align_s_per_step": round(align_s / args.steps, 4), "reduce_s_per_step": round(reduce_s / args.steps, 5),
+                      "winners_s_per_step": round(winners_s / args.steps, 4), "chunks": int(last["chunks"]),
+                      "generate_inputs_s": round(gen_s, 1)},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "kernel": "sw_sweep_winmax_kernel (sum over rank 0's chunks, three streams)",
+                         "kernel_ms_per_step": round(sweep_ms / args.steps, 3), "alg_bytes_per_step_rank0": bytes_rank,
+                         "traceback_ms_per_step": round(tb_ms / args.steps, 3)},
+            "reduce": {"best_total": int(last["best"]), "winners": [int(w) for w in last["winners"]][:8],
+                       "top_k": [[int(a), int(b_)] for a, b_ in last["top"]], "winner_sites_rank0": int(last["winner_sites"])},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            from oracle import sw_oracle as orc
+            cores = effective_cores()
+            # bounded sample: the first references of the set x all reads, ~15 s of CPU work; totals compared with the GPU's
+            per_ref = float(np.mean(lengths[:64])) * sum(len(q) for q in reads)
+            n_s = int(max(8, min(len(refs), 3.0e9 * cores / 16 * 15 / per_ref)))
+            r = orc.bench(refs[:n_s], reads, nthreads=cores, per_pair=True)
+            want = np.asarray(r["pair_score"], dtype=np.int64).reshape(n_s, len(reads)).sum(axis=1)
+            pos = {int(g): k for k, g in enumerate(local_ids)}
+            got = np.array([int(last["totals"][pos[g]]) for g in range(n_s)], dtype=np.int64)
+            gc = r["cells"] / r["seconds"] / 1e9
+            out["cpu_baseline"] = {"value": round(gc, 4), "unit": "GCUPS", "cores": cores, "kind": "port",
+                                   "sample": "the first %d references x all %d reads (%.1f s); C restatement of SmithWaterman.OptAlignments, "
+                                             "persistent pool of %d pthreads" % (n_s, len(reads), r["seconds"], cores)}
+            out["check"] = {"refs_compared": n_s, "mismatches": int((want != got).sum()),
+                            "compared": "per-reference totals over all reads, GPU vs oracle, same run"}
+        print(json.dumps(out), flush=True)
+    ctx.close()
 
 
 def cpu_baseline(refs, reads, gpu_scores, gpu_naln):

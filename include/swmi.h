@@ -107,6 +107,9 @@ void        swmi_default_params(swmi_params *p);
  *                of at most 2560 -- is swept in the TRANSPOSED layout (reference columns on the lanes, the read streaming
  *                through) and traced back in the same launch (sw_tfused_kernel: block tasks and walk items shared by the
  *                wavefronts of a workgroup); 0 or -1 (default): never -- measured slower than the two-kernel pipeline.
+ * stream_keep_records (default 1): 0 = a stream drops every chunk's alignment records once its scores, counts and totals are
+ *                taken -- for a driver that reduces to the winning references and aligns those again (Distribution.java:341-353
+ *                discards every other reference's alignments too); the alignment accessors of such chunks fail.
  * Further knobs: spin_us (how long a run polls its stream before it blocks, default 2000); col_chunks (0 automatic,
  * 1 never, N > 1 force up to N column chunks per pair: a launch of few pairs with long references is swept by several
  * wavefronts per pair); debug_strip_spins / debug_reverse_strips (tests of the strip pipeline's give-up path). */

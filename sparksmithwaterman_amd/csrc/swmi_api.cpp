@@ -69,12 +69,17 @@ int swmi_io_fail(int code, const std::string &msg) { return fail(code, "%s", msg
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
+    // Allocations leave headroom (x 1.5 for workspaces of 256 MiB and more, x 1.25 when growing): a stream's chunks differ by a
+    // few per cent, and freeing and re-allocating a 20 GB workspace for every new largest chunk stalled every slot of a stream
+    // for 1.5-3 s each time (hipFree / hipMalloc hold a device-wide lock; profiles/r03/config3_host_breakdown.txt).
     int reserve(size_t bytes) {
         if (bytes <= cap) return SWMI_OK;
-        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
-        hipError_t e = hipMalloc(&p, bytes);
+        size_t want = bytes >= (256u << 20) ? bytes + bytes / 2 : bytes;      // (big workspaces: the first allocation already leaves room)
+        if (p) { want = std::max(want, cap + cap / 4); (void)hipFree(p); p = nullptr; cap = 0; }
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess && want > bytes) { want = bytes; e = hipMalloc(&p, want); }
         if (e != hipSuccess) { p = nullptr; return fail(SWMI_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); }
-        cap = bytes;
+        cap = want;
         return SWMI_OK;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
@@ -91,7 +96,7 @@ struct PinnedBuf {
     size_t cap = 0;
     int reserve(size_t bytes) {
         if (bytes <= cap) return SWMI_OK;
-        if (p) { (void)hipHostFree(p); p = nullptr; dp = nullptr; cap = 0; }
+        if (p) { bytes = std::max(bytes, cap + cap / 4); (void)hipHostFree(p); p = nullptr; dp = nullptr; cap = 0; }      // (headroom: see DevBuf)
         hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocMapped);
         if (e != hipSuccess) { p = nullptr; return fail(SWMI_ERR_NOMEM, "hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); }
         e = hipHostGetDevicePointer(&dp, p, 0);
@@ -137,6 +142,8 @@ struct swmi_ctx {
                                             // durations, as rocprofv3 shows them) -- measured 8-12 us per run DEARER than three hipEventRecord, so off
     int tfused = -1;                        // transposed sweep + traceback by one wavefront per pair (swmi_tfused.hip): -1 automatic, 0 never, 1 whenever a pair qualifies
     int resident = -1;                      // small pairs handled by one wavefront with the direction field in LDS: -1 automatic, 0 never, 1 whenever it fits
+    int stream_keep_records = 1;            // streams: 0 = a chunk's alignment records are dropped once its scores and counts are taken (a driver
+                                            // that only needs totals and re-aligns its few winners, Distribution.java:341-353)
     int device_strings = 1;                 // the traceback kernels write both aligned strings behind every record (swmi_emit.h); 0: 2-bit ops only, strings built by the host
     bool cell_cap_set = false;              // cell_cap given by the caller (otherwise small launches get longer lists)
     // swmi_batch_run_async: one run in flight on the context's own host thread
@@ -247,6 +254,7 @@ struct swmi_batch {
     std::vector<RawChunk> raw_chunks;
     bool indexed = false;
     bool rec_strings = false;               // the records of the last run carry both aligned strings (option device_strings)
+    bool records_dropped = false;           // a streamed chunk whose records were not kept (option stream_keep_records = 0)
     std::vector<HostAln> alns;              // grouped by pair, ordered as OptAlignments returns them
     std::vector<char> str_buf;              // every alignment's two NUL-terminated strings, at fixed offsets (str_at)
     std::vector<uint64_t> str_at;           // per alignment: offset of its reference-side string; the read side follows it
@@ -372,6 +380,8 @@ extern "C" int swmi_set_option(swmi_ctx *ctx, const char *name, int64_t value) {
     } else if (!strcmp(name, "resident")) {
         if (value < -1 || value > 1) return fail(SWMI_ERR_INVALID, "resident must be -1 (automatic), 0 or 1");
         ctx->resident = (int)value;
+    } else if (!strcmp(name, "stream_keep_records")) {
+        ctx->stream_keep_records = value != 0;
     } else if (!strcmp(name, "device_strings")) {
         ctx->device_strings = value != 0;
     } else if (!strcmp(name, "tb_split")) {
@@ -544,7 +554,7 @@ struct RunState {
     TraceArgs ta{};
     float fill_ms = 0, tb_ms = 0, d2h_ms = 0;
     uint32_t launches = 0;
-    double enqueue_us = 0, wait_us = 0, copyout_us = 0;
+    double enqueue_us = 0, wait_us = 0, copyout_us = 0, prep_us = 0, prep_upload_us = 0;
     bool one_wave_sweep = false;            // the strip pipeline gave up once in this run: long reads are swept by one wavefront
     bool tb_split = false;                  // mode 1: detect per window + walk per alignment instead of one workgroup per pair
     bool defer_copy = false;                // this launch is the whole run: its records may stay in the pinned block
@@ -610,6 +620,7 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
     uint32_t tf_max_m = 0, tf_max_n = 0, tf_max_path = 0;
     const uint32_t res_cell_cap = 128;
     swmi_batch::Prep &pr = b->prep;
+    const auto p0 = std::chrono::steady_clock::now();
     const bool prepared = pr.valid && pr.lo == lo && pr.hi == hi && pr.work == (const void *)work.data() && pr.mode == b->eff_mode &&
                           memcmp(&pr.params, &b->params, sizeof(swmi_params)) == 0 && b->pairs_dev_ptr == b->d_pairs.p &&
                           b->pairs_on_device.size() == np * sizeof(PairDesc) && pr.col_chunks_opt == ctx->col_chunks &&
@@ -758,6 +769,7 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
     }
     if (b->eff_mode == 1) win_off[np] = (uint32_t)std::min<uint64_t>(n_windows, 0xFFFFFFFFu);
     }
+    const auto p1 = std::chrono::steady_clock::now();
     if (!prepared && b->eff_mode == 1) {
         if ((rc = b->d_win_off.reserve((np + 1) * sizeof(uint32_t)))) return rc;
         HIP_TRY(hipMemcpyAsync(b->d_win_off.p, win_off.data(), (np + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
@@ -843,6 +855,8 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
     }
 
     const auto c0 = std::chrono::steady_clock::now();
+    rs.prep_us += std::chrono::duration<double, std::micro>(p1 - p0).count();
+    rs.prep_upload_us += std::chrono::duration<double, std::micro>(c0 - p1).count();
     uint64_t arena_cap = std::max<uint64_t>(np * ctx->arena_words_per_pair, 1024);
     uint64_t tab_cap = std::max<uint64_t>(np * ctx->recs_per_pair_x16 / 16 + 64, 256);
     std::vector<uint8_t> saved_outs;       // PairOut block carried across an arena re-allocation
@@ -1250,6 +1264,8 @@ static int settle_raw(swmi_batch *b) {
 // Turns the record tables of the last run into per-pair alignment lists (first use of an alignment accessor).
 static int ensure_indexed(swmi_batch *b) {
     if (b->indexed) return SWMI_OK;
+    if (b->records_dropped)
+        return fail(SWMI_ERR_INVALID, "this chunk's alignment records were not kept (option stream_keep_records = 0): scores, counts and totals only");
     const std::vector<Work> &work = b->work;
     // every launch's table (dense, read sequentially) with the arena its payload offsets refer to; the only launch of a
     // run may still sit in the pinned block the kernels wrote: indexed where it is, nothing copied
@@ -1547,8 +1563,8 @@ extern "C" int swmi_batch_run(swmi_ctx *ctx, swmi_batch *b, const swmi_params *p
     b->timing.dir_bytes = dir_bytes;
     b->has_run = true;
     if (host_dbg)
-        fprintf(stderr, "[swmi host] setup %.1f us, chunks (launch+wait+parse) %.1f us [enqueue %.1f, wait %.1f, copy-out %.1f], grouping %.1f us\n",
-                us(h0, h1), us(h1, h2), rs.enqueue_us, rs.wait_us, rs.copyout_us, us(h2, now()));
+        fprintf(stderr, "[swmi host] setup %.1f us, chunks (launch+wait+parse) %.1f us [prepare %.1f, its uploads %.1f, enqueue %.1f, wait %.1f, copy-out %.1f], grouping %.1f us\n",
+                us(h0, h1), us(h1, h2), rs.prep_us, rs.prep_upload_us, rs.enqueue_us, rs.wait_us, rs.copyout_us, us(h2, now()));
     return SWMI_OK;
 }
 
@@ -1973,6 +1989,7 @@ struct swmi_stream {
     std::vector<uint64_t> read_off;
     uint32_t n_reads = 0;
     uint64_t chunk_bytes = 32ull << 20;
+    bool keep_records = true;
     // slots
     struct Slot { swmi_ctx *ctx = nullptr; swmi_batch *shell = nullptr; std::thread th; };
     std::vector<Slot> slots;
@@ -2022,6 +2039,7 @@ static int stream_process(swmi_stream *s, swmi_stream::Slot &sl, StreamChunk *c)
     const auto t1 = std::chrono::steady_clock::now();
     if ((rc = swmi_batch_run(sl.ctx, b, &s->params))) return rc;
     const double run = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
+    const auto t2 = std::chrono::steady_clock::now();
     // results-only batch of this chunk
     std::unique_ptr<swmi_batch> r(new swmi_batch);
     r->n_refs = n_refs; r->n_reads = s->n_reads;
@@ -2033,10 +2051,15 @@ static int stream_process(swmi_stream *s, swmi_stream::Slot &sl, StreamChunk *c)
     r->work = std::move(b->work); b->work.clear(); b->work_mode = -1;
     r->work_mode = (int)r->eff_mode;
     r->pairs = std::move(b->pairs);
-    (void)settle_raw(b);
-    r->raw = std::move(b->raw);
-    r->rtab = std::move(b->rtab);
-    r->raw_chunks = std::move(b->raw_chunks);
+    if (s->keep_records) {
+        (void)settle_raw(b);
+        r->raw = std::move(b->raw);
+        r->rtab = std::move(b->rtab);
+        r->raw_chunks = std::move(b->raw_chunks);
+    } else {
+        r->records_dropped = true;
+        b->raw_ext = nullptr; b->rtab_ext = nullptr;
+    }
     r->rec_strings = b->rec_strings;
     r->indexed = false;
     r->ref_view_ready.assign(n_refs, 0);
@@ -2047,6 +2070,11 @@ static int stream_process(swmi_stream *s, swmi_stream::Slot &sl, StreamChunk *c)
     else r->ref_bytes = std::move(c->keep);
     b->pairs.clear(); b->raw.clear(); b->rtab.clear(); b->raw_chunks.clear(); b->has_run = false;
     std::lock_guard<std::mutex> g(s->mu);
+    {
+        static const bool host_dbg = getenv("SWMI_DEBUG_HOST") != nullptr;
+        if (host_dbg) fprintf(stderr, "[swmi stream] chunk %u: %u refs, run %.1f ms, results moved out of the slot in %.1f ms\n", c->id, n_refs, run,
+                              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t2).count());
+    }
     if (s->results.size() <= c->id) s->results.resize(c->id + 1, nullptr);
     s->results[c->id] = r.release();
     s->stats.run_ms += run;
@@ -2096,6 +2124,7 @@ extern "C" int swmi_stream_open(swmi_ctx *ctx, const swmi_params *p, const uint8
     s->read_off.assign(read_off, read_off + n_reads + 1);
     s->read_bytes.assign(read_bytes, read_bytes + read_off[n_reads]);
     if (chunk_bytes) s->chunk_bytes = std::max<uint64_t>(chunk_bytes, 1 << 16);
+    s->keep_records = ctx->stream_keep_records != 0;
     s->slots.resize(slots);
     for (auto &sl : s->slots) {
         if ((rc = swmi_create(ctx->device, &sl.ctx))) { swmi_stream_close(s.release()); return rc; }
@@ -2104,6 +2133,7 @@ extern "C" int swmi_stream_open(swmi_ctx *ctx, const swmi_params *p, const uint8
         sl.ctx->profiling = ctx->profiling; sl.ctx->mode = ctx->mode; sl.ctx->zero_copy = ctx->zero_copy;
         sl.ctx->tb_split = ctx->tb_split; sl.ctx->col_chunks = ctx->col_chunks; sl.ctx->resident = ctx->resident; sl.ctx->tfused = ctx->tfused;
         sl.ctx->auto_ties_x100 = ctx->auto_ties_x100; sl.ctx->arena_words_per_pair = ctx->arena_words_per_pair;
+        sl.ctx->device_strings = ctx->device_strings;
         sl.ctx->spin_us = 50;                    // (a chunk takes milliseconds: the slot threads mostly block)
         sl.shell = new swmi_batch;
     }

@@ -167,7 +167,7 @@ struct TraceArgs {
     PairOut        *out_host;    // zero-copy results: host-mapped mirror of out[] (written by slot 0 of every pair), or null
     uint32_t       *ovf_host;    // zero-copy results: set to 1 when a record did not fit the (host-mapped) arena
     uint32_t        mode;        // same as FillArgs.mode
-    uint32_t        pad2;
+    uint32_t        pad2;        // set by the launcher of sw_traceback_winmax_kernel: a second set of window tiles is there (speculative staging)
     // split traceback (mode 1, tie-heavy or tiny batches): sw_detect_windows_kernel lists the maximum cells one wavefront
     // per candidate WINDOW and queues one walk item per cell, sw_walk_items_kernel walks one alignment per wavefront
     const uint32_t *win_off;     // per pair of the launch: index of its first window among all windows (n_pairs + 1 entries)

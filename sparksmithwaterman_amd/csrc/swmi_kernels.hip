@@ -1088,7 +1088,7 @@ __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDes
                                                uint32_t *__restrict__ lds, uint32_t *__restrict__ lds_tile,
                                                volatile uint32_t *__restrict__ shared, const uint32_t ts,
                                                uint32_t pre_wlo = 0xFFFFFFFFu, const bool read_staged = false,
-                                               const uint4 *__restrict__ one = nullptr) {
+                                               const uint4 *__restrict__ one = nullptr, uint32_t *__restrict__ lds_tile_alt = nullptr) {
     const SeqDesc rd = A.refs[pd.ref_id];
     const SeqDesc qd = A.reads[pd.read_id];
     const uint32_t n = rd.len, m = qd.len;
@@ -1115,6 +1115,28 @@ __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDes
     const uint8_t *read_b = reinterpret_cast<const uint8_t *>(lds_read);
     const uint8_t *ref_b = reinterpret_cast<const uint8_t *>(lds_ref);
     uint32_t req_seq = 0, req_expected = 0;                    // COOP: requests published / windows expected back so far
+    // COOP with a second tile buffer (lds_tile_alt): SPECULATIVE staging.  A path only ever moves towards smaller steps, so
+    // the span the walk will need next is the one just before the current one: the team's helpers re-sweep it into the other
+    // buffer WHILE the walker walks, and the walker finds it ready when it crosses the boundary (it swaps buffers instead of
+    // waiting ~7 k cycles for a re-sweep).  A span whose walk ends early costs the helpers -- otherwise idle -- one re-sweep.
+    uint32_t *tile_cur = lds_tile, *tile_alt = lds_tile_alt;
+    uint32_t spec_wlo = 0xFFFFFFFFu, spec_hi = 0u, spec_rv0 = 0u, spec_rv1 = 0u;
+    auto team_wait = [&]() {                                   // every window requested so far has been delivered
+        while (__hip_atomic_load(const_cast<uint32_t *>(&shared[20u + slot]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < req_expected)
+            __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
+    // request {flags: bit 0 = buffer (0: the team's first, 1: its second), bit 1 = the walker takes no window of it, bits 2.. =
+    // the strip; first block; windows}; the helpers poll the sequence number (coop_helper)
+    auto team_request = [&](uint32_t flags, uint32_t first_block, uint32_t nq, uint32_t delivered) {
+        ++req_seq;
+        req_expected += delivered;
+        if (lane == 0) {
+            shared[4u + 4u * slot] = flags; shared[5u + 4u * slot] = first_block; shared[6u + 4u * slot] = nq;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __hip_atomic_store(const_cast<uint32_t *>(&shared[7u + 4u * slot]), req_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    };
 
     const unsigned long long tk0 = A.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
     unsigned long long tk_walk = 0, tk_stage = 0, n_steps = 0, n_iters = 0;
@@ -1176,45 +1198,65 @@ __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDes
                     wlo = whi - whi % SWMI_CK_BLOCKS;                              // windows start at checkpoints
                     nb = SWMI_CK_BLOCKS;
                 }
+                // COOP: the span the helpers have been re-sweeping since the last staging, if the walk arrived there
+                bool use_spec = false;
+                if (COOP && spec_wlo != 0xFFFFFFFFu) {
+                    const uint32_t wtop = whi - whi % SWMI_CK_BLOCKS;
+                    if (s == 0u && wtop + SWMI_CK_BLOCKS == spec_hi) { use_spec = true; wlo = spec_wlo; nb = spec_hi - spec_wlo; }
+                }
                 // COOP: the span of the first staging was already re-swept while wave 0 listed the maximum cells
-                const bool prestaged = TMODE == 1 && pre_wlo == wlo && s == 0u;
+                const bool prestaged = TMODE == 1 && pre_wlo == wlo && s == 0u && !use_spec;
                 pre_wlo = 0xFFFFFFFFu;
                 const int clo = (int)(16u * wlo) - 63;
                 const uint32_t cw0 = clo > 0 ? (uint32_t)clo >> 2 : 0u;           // first dword of the reference window
                 const uint32_t cw1 = (16u * (wlo + nb) - 1u) >> 2;
                 WAVE_SYNC();
-                if (!prestaged) {
+                if (use_spec) {
+                    const unsigned long long tq0 = A.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
+                    team_wait();
+                    if (A.dbg) tk_walk += (__builtin_amdgcn_s_memtime() - tq0) << 32;
+                    uint32_t *t = tile_cur; tile_cur = tile_alt; tile_alt = t;
+                    lds_ref[lane] = spec_rv0;
+                    if (lane + WAVE < SWMI_TB_REFWIN_WORDS) lds_ref[lane + WAVE] = spec_rv1;
+                    WAVE_SYNC();
+                } else if (!prestaged) {
                     // the slice of the reference: loads issued now, stored to LDS after the re-sweep (at most 2 dwords per lane)
                     const uint32_t rx0 = cw0 + lane, rx1 = rx0 + WAVE, rlim = (n + 3u) / 4u;
                     const uint32_t rv0 = (rx0 <= cw1 && rx0 < rlim) ? refw[rx0] : 0u;
                     const uint32_t rv1 = (rx1 <= cw1 && rx1 < rlim) ? refw[rx1] : 0u;
                     if (TMODE == 0) {
                         const uint32_t *__restrict__ src = dirp + s * G.strip_words + (uint64_t)wlo * R * WAVE + lane;
-                        for (uint32_t x = 0; x < nb * R; ++x) lds_tile[x * WAVE + lane] = src[(uint64_t)x * WAVE];
+                        for (uint32_t x = 0; x < nb * R; ++x) tile_cur[x * WAVE + lane] = src[(uint64_t)x * WAVE];
                     } else {
                         if (COOP) {
+                            team_wait();                                           // (a speculative request nobody needs any more)
                             const uint32_t nq = nb / SWMI_CK_BLOCKS;
-                            ++req_seq;
-                            req_expected += nq - 1u;                               // helpers 1 .. nq-1 deliver one window each
-                            if (lane == 0) {
-                                shared[4u + 4u * slot] = s; shared[5u + 4u * slot] = wlo; shared[6u + 4u * slot] = nq;
-                                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                                __hip_atomic_store(const_cast<uint32_t *>(&shared[7u + 4u * slot]), req_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            }
+                            team_request((tile_cur == lds_tile ? 0u : 1u) | (s << 2), wlo, nq, nq - 1u);     // helpers 1 .. nq-1 deliver one window each
                         }
-                        (void)replay_any<R, false, FULL>(A, pd, n, m, acgt, refw, readw, G, s, wlo, lane, lds_tile, 0, 0u, nullptr, 0u);
+                        (void)replay_any<R, false, FULL>(A, pd, n, m, acgt, refw, readw, G, s, wlo, lane, tile_cur, 0, 0u, nullptr, 0u);
                     }
                     lds_ref[lane] = rv0;
                     if (lane + WAVE < SWMI_TB_REFWIN_WORDS) lds_ref[lane + WAVE] = rv1;
                     if (COOP) {
                         // wait for the helpers' windows
                         const unsigned long long tq0 = A.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
-                        while (__hip_atomic_load(const_cast<uint32_t *>(&shared[20u + slot]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < req_expected)
-                            __builtin_amdgcn_s_sleep(1);
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                        team_wait();
                         if (A.dbg) tk_walk += (__builtin_amdgcn_s_memtime() - tq0) << 32;     // (waiting counted in the upper half)
                     }
                     WAVE_SYNC();
+                }
+                spec_wlo = 0xFFFFFFFFu;
+                if (COOP && tile_alt != nullptr && ts > 1u && wlo > 0u && s == 0u) {
+                    // the helpers start on the span to the left of this one, ts - 1 windows of it, while the walker walks
+                    const uint32_t have = wlo / SWMI_CK_BLOCKS, nq = have < ts - 1u ? have : ts - 1u;
+                    spec_hi = wlo;
+                    spec_wlo = wlo - nq * SWMI_CK_BLOCKS;
+                    const int sclo = (int)(16u * spec_wlo) - 63;
+                    const uint32_t scw0 = sclo > 0 ? (uint32_t)sclo >> 2 : 0u, scw1 = (16u * spec_hi - 1u) >> 2;
+                    const uint32_t rx0 = scw0 + lane, rx1 = rx0 + WAVE, rlim = (n + 3u) / 4u;
+                    spec_rv0 = (rx0 <= scw1 && rx0 < rlim) ? refw[rx0] : 0u;      // its slice of the reference: held in registers meanwhile
+                    spec_rv1 = (rx1 <= scw1 && rx1 < rlim) ? refw[rx1] : 0u;
+                    team_request((tile_alt == lds_tile ? 0u : 1u) | 2u, spec_wlo, nq, nq);
                 }
                 const int tmin = (int)(16u * wlo);
                 const unsigned long long tw0 = A.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -1241,7 +1283,7 @@ __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDes
                     const int tx = (int)jj - 1 + (int)lx;
                     const bool valid = rho_x >= 0 && j > nb && tx >= tmin;         // same strip, inside the matrix, inside the staged span
                     // all three LDS reads are issued together (one latency); lanes without a cell read element 0
-                    const uint32_t dw = lds_tile[valid ? (((uint32_t)tx >> 4) - wlo) * (R * WAVE) + kx * WAVE + lx : 0u];
+                    const uint32_t dw = tile_cur[valid ? (((uint32_t)tx >> 4) - wlo) * (R * WAVE) + kx * WAVE + lx : 0u];
                     const uint32_t rc = ref_b[valid ? (jj - 1u) - 4u * cw0 : 0u];
                     const uint32_t qc = read_b[valid ? i - 1u - na : 0u];
                     const uint32_t d = (dw >> (2u * (15u - ((uint32_t)tx & 15u)))) & 3u;
@@ -1299,7 +1341,7 @@ __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDes
                     const bool valid = grp < 3u && rho_x >= 0 && j > dj + x && tx >= tmin;
                     // all three LDS reads are issued together (one latency): direction word, reference code, read code.
                     // Lanes without a cell read element 0 instead of branching around the loads.
-                    const uint32_t dw = lds_tile[valid ? (((uint32_t)tx >> 4) - wlo) * (R * WAVE) + kx * WAVE + lx : 0u];
+                    const uint32_t dw = tile_cur[valid ? (((uint32_t)tx >> 4) - wlo) * (R * WAVE) + kx * WAVE + lx : 0u];
                     const uint32_t rc = ref_b[valid ? (jj - 1u) - 4u * cw0 : 0u];
                     const uint32_t qc = read_b[valid ? i - 1u - di - x : 0u];
                     const uint32_t d = (dw >> (2u * (15u - ((uint32_t)tx & 15u)))) & 3u;
@@ -1399,8 +1441,8 @@ __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDes
             const uint32_t words = swmi_payload_words(n_ops, A.raw != nullptr);
             const SwmiReserve rsv = swmi_reserve_issue(A, lane, words, 1u);
             // while the reservation is on its way: this lane's first dword of packed ops, and the last 256 characters of
-            // GetAlignment's two strings (SmithWaterman.java:418-431) from the caller's own bytes.  The walker's direction tile
-            // is free between two walks (its helpers wait for the next request) and serves as scratch.
+            // GetAlignment's two strings (SmithWaterman.java:418-431) from the caller's own bytes.  The walker's current direction
+            // tile is free between two walks (a speculative span goes to the other one) and serves as scratch.
             const bool staged = n_ops <= 4u * A.lds_words;
             auto pack16 = [&](uint32_t w) {
                 uint32_t packed = 0;
@@ -1415,7 +1457,7 @@ __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDes
                 return packed;
             };
             const uint32_t packed0 = (staged && lane < opw) ? pack16(lane) : 0u;
-            SwmiStrings<SwmiOpsPerByte> strs(SwmiOpsPerByte{ops_b}, staged ? n_ops : 0u, ci, cj, raw_ref, raw_read, lane, lds_tile);
+            SwmiStrings<SwmiOpsPerByte> strs(SwmiOpsPerByte{ops_b}, staged ? n_ops : 0u, ci, cj, raw_ref, raw_read, lane, tile_cur);
             const uint32_t sw = strs.words(), ctop = strs.n_chunks();
             uint32_t wr0 = 0, wq0 = 0;
             if (A.raw && staged) strs.chunk(ctop - 1u, wr0, wq0);
@@ -1451,7 +1493,7 @@ __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDes
 // The helper side of COOP: wave `wave` >= nw serves team (wave - nw) % nw as its window number 1 + (wave - nw) / nw.
 template <int R>
 __device__ __forceinline__ void coop_helper(const TraceArgs &A, const PairDesc pd, const uint32_t lane, const uint32_t wave,
-                                            const uint32_t nw, const uint32_t ts,
+                                            const uint32_t nw, const uint32_t ts, const uint32_t n_waves_all,
                                             uint32_t *__restrict__ tiles, volatile uint32_t *__restrict__ shared) {
     const SeqDesc rd = A.refs[pd.ref_id];
     const SeqDesc qd = A.reads[pd.read_id];
@@ -1461,8 +1503,6 @@ __device__ __forceinline__ void coop_helper(const TraceArgs &A, const PairDesc p
     const StripGeom G = strip_geom<R>(m, n, 1u);
     const bool acgt = rd.acgt && qd.acgt && SWMI_SCORES_FIT(A);
     const uint32_t team = (wave - nw) % nw, q = 1u + (wave - nw) / nw;
-    uint32_t *__restrict__ tile = tiles + (team * ts + q) * (SWMI_CK_BLOCKS * SWMI_RMAX * WAVE) ;
-    (void)tile;
     uint32_t last = 0;
     for (;;) {
         uint32_t seq;
@@ -1471,11 +1511,16 @@ __device__ __forceinline__ void coop_helper(const TraceArgs &A, const PairDesc p
         if (seq == 0xFFFFFFFFu) break;
         last = seq;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        const uint32_t s = shared[4u + 4u * team], wlo = shared[5u + 4u * team], nq = shared[6u + 4u * team];
-        if (q < ts && q < nq) {
-            (void)replay_any<R, false, false>(A, pd, n, m, acgt, refw, readw, G, s, wlo + q * SWMI_CK_BLOCKS, lane,
-                                       tiles + team * ts * (SWMI_CK_BLOCKS * SWMI_RMAX * WAVE) + q * SWMI_CK_BLOCKS * R * WAVE,
-                                       0, 0u, nullptr, 0u);
+        // request: flags bit 0 = the team's second buffer, bit 1 = speculative (the walker takes no window: helper q takes window
+        // q-1), bits 2.. = the strip
+        const uint32_t flags = shared[4u + 4u * team], wlo = shared[5u + 4u * team], nq = shared[6u + 4u * team];
+        const uint32_t s = flags >> 2;
+        const uint32_t win = (flags & 2u) ? q - 1u : q;
+        if (q < ts && win < nq) {
+            uint32_t *__restrict__ base = ((flags & 1u) ? tiles + n_waves_all * (SWMI_CK_BLOCKS * SWMI_RMAX * WAVE) : tiles) +
+                                          team * ts * (SWMI_CK_BLOCKS * SWMI_RMAX * WAVE);
+            (void)replay_any<R, false, false>(A, pd, n, m, acgt, refw, readw, G, s, wlo + win * SWMI_CK_BLOCKS, lane,
+                                       base + win * SWMI_CK_BLOCKS * R * WAVE, 0, 0u, nullptr, 0u);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (lane == 0) atomicAdd(const_cast<uint32_t *>(&shared[20u + team]), 1u);
         }
@@ -1635,7 +1680,9 @@ __device__ __forceinline__ uint32_t winmax_detect(const TraceArgs &A, const Pair
 
 // mode 1: one workgroup of SWMI_TB_WAVES waves = ONE pair.  Wave 0 first lists the maximum cells (detect_cells),
 // the workgroup meets at a barrier, then min(cells, 4) waves walk the alignments and the others help them.
-extern "C" __global__ void __launch_bounds__(WAVE * SWMI_TB_WAVES)
+// (4 waves per SIMD = at most 128 VGPRs: at the headline the 1000 workgroups of four waves must ALL be resident, or the launch
+//  grows a second round of workgroups -- at 130 VGPRs it took 0.092 ms instead of 0.073)
+extern "C" __global__ void __launch_bounds__(WAVE * SWMI_TB_WAVES) __attribute__((amdgpu_waves_per_eu(4, 4)))
 sw_traceback_winmax_kernel(const TraceArgs A) {
     extern __shared__ uint32_t wm_lds[];
     const uint32_t pair = blockIdx.x;
@@ -1657,7 +1704,10 @@ sw_traceback_winmax_kernel(const TraceArgs A) {
     uint32_t *tiles = wm_lds + 32;
     const uint32_t R = swmi_rows_per_lane(A.reads[pd.read_id].len);
     const uint32_t ccap = A.cells_cap ? A.cells_cap[pd.out_id] : A.cell_cap;
-    uint32_t *walker_lds0 = tiles + n_waves * WIN_WORDS;
+    // (A.pad2: the launcher reserved a SECOND set of window tiles for speculative staging -- traceback_pair)
+    const uint32_t tile_sets = A.pad2 ? 2u : 1u;
+    uint32_t *tiles2 = A.pad2 ? tiles + n_waves * WIN_WORDS : nullptr;
+    uint32_t *walker_lds0 = tiles + tile_sets * n_waves * WIN_WORDS;
     if (!swmi_common_pair(A, A.refs[pd.ref_id], A.reads[pd.read_id])) {
         // a byte alphabet, the DistributedSW tie order or a read of several strips: the plain scheme -- wave 0 lists the
         // cells, then up to four independent walkers, one window at a time -- with every kernel variant available
@@ -1705,7 +1755,7 @@ sw_traceback_winmax_kernel(const TraceArgs A) {
     if (ts == 1u) {
         // no helpers to share the re-sweeps with: the walkers run independently, one window at a time
         if (wave >= nw) return;
-        uint32_t *lds = tiles + n_waves * WIN_WORDS + wave * per_walker;
+        uint32_t *lds = walker_lds0 + wave * per_walker;
         uint32_t *tile = tiles + wave * WIN_WORDS;
         if (R == 1)      traceback_pair<1, 1, false, false>(A, pd, po, lane, wave, nw, lds, tile, nullptr, 1u, pre_wlo, true);
         else if (R == 2) traceback_pair<2, 1, false, false>(A, pd, po, lane, wave, nw, lds, tile, nullptr, 1u, pre_wlo, true);
@@ -1714,17 +1764,18 @@ sw_traceback_winmax_kernel(const TraceArgs A) {
         return;
     }
     if (wave < nw) {
-        uint32_t *lds = tiles + n_waves * WIN_WORDS + wave * per_walker;
+        uint32_t *lds = walker_lds0 + wave * per_walker;
         uint32_t *tile = tiles + wave * ts * WIN_WORDS;
-        if (R == 1)      traceback_pair<1, 1, true, false>(A, pd, po, lane, wave, nw, lds, tile, shared, ts, pre_wlo, true);
-        else if (R == 2) traceback_pair<2, 1, true, false>(A, pd, po, lane, wave, nw, lds, tile, shared, ts, pre_wlo, true);
-        else if (R == 3) traceback_pair<3, 1, true, false>(A, pd, po, lane, wave, nw, lds, tile, shared, ts, pre_wlo, true);
-        else             traceback_pair<4, 1, true, false>(A, pd, po, lane, wave, nw, lds, tile, shared, ts, pre_wlo, true);
+        uint32_t *tile2 = tiles2 ? tiles2 + wave * ts * WIN_WORDS : nullptr;
+        if (R == 1)      traceback_pair<1, 1, true, false>(A, pd, po, lane, wave, nw, lds, tile, shared, ts, pre_wlo, true, nullptr, tile2);
+        else if (R == 2) traceback_pair<2, 1, true, false>(A, pd, po, lane, wave, nw, lds, tile, shared, ts, pre_wlo, true, nullptr, tile2);
+        else if (R == 3) traceback_pair<3, 1, true, false>(A, pd, po, lane, wave, nw, lds, tile, shared, ts, pre_wlo, true, nullptr, tile2);
+        else             traceback_pair<4, 1, true, false>(A, pd, po, lane, wave, nw, lds, tile, shared, ts, pre_wlo, true, nullptr, tile2);
     } else {
-        if (R == 1)      coop_helper<1>(A, pd, lane, wave, nw, ts, tiles, shared);
-        else if (R == 2) coop_helper<2>(A, pd, lane, wave, nw, ts, tiles, shared);
-        else if (R == 3) coop_helper<3>(A, pd, lane, wave, nw, ts, tiles, shared);
-        else             coop_helper<4>(A, pd, lane, wave, nw, ts, tiles, shared);
+        if (R == 1)      coop_helper<1>(A, pd, lane, wave, nw, ts, n_waves, tiles, shared);
+        else if (R == 2) coop_helper<2>(A, pd, lane, wave, nw, ts, n_waves, tiles, shared);
+        else if (R == 3) coop_helper<3>(A, pd, lane, wave, nw, ts, n_waves, tiles, shared);
+        else             coop_helper<4>(A, pd, lane, wave, nw, ts, n_waves, tiles, shared);
     }
 }
 
@@ -2172,12 +2223,20 @@ extern "C" hipError_t swmi_launch_traceback(const TraceArgs *a, hipStream_t st, 
         static int big = getenv("SWMI_TB_BIG") ? atoi(getenv("SWMI_TB_BIG")) : 10000;   // measured crossover: between 8 k and 16 k pairs
         const uint32_t n_waves = forced ? (uint32_t)forced : (a->n_pairs <= 512u ? SWMI_TB_WAVES : a->n_pairs <= (uint32_t)big ? 4u : 1u);
         const size_t n_walkers = n_waves < SWMI_TB_SLOTS ? n_waves : SWMI_TB_SLOTS;
-        const size_t words = 32 + (size_t)n_waves * SWMI_CK_BLOCKS * SWMI_RMAX * WAVE +
-                             n_walkers * ((size_t)a->lds_words + a->lds_read_words + SWMI_TB_REFWIN_WORDS);
+        const size_t tiles = (size_t)n_waves * SWMI_CK_BLOCKS * SWMI_RMAX * WAVE;
+        size_t words = 32 + tiles + n_walkers * ((size_t)a->lds_words + a->lds_read_words + SWMI_TB_REFWIN_WORDS);
+        // speculative staging (traceback_pair): a second set of tiles, while teams have helpers and the block still fits.
+        // Measured (profiles/r03/ab_spec_staging.txt): 250 pairs 0.0554 -> 0.0491 ms, 500 pairs 0.0600 -> 0.0593, 1000 pairs
+        // 0.0735 -> 0.0768 -- from about 500 pairs on the SIMDs are shared by the waves of several pairs and the helpers'
+        // extra re-sweeps (a span whose walk ends early is wasted) cost other pairs' walkers more than the waits they save.
+        static const int spec_opt = getenv("SWMI_TB_SPEC") ? atoi(getenv("SWMI_TB_SPEC")) : 1;      // 0 never, 1 automatic, 2 always
+        TraceArgs t = *a;
+        t.pad2 = (spec_opt && (spec_opt == 2 || a->n_pairs <= 384u) && n_waves > 1u && (words + tiles) * sizeof(uint32_t) <= 160u * 1024u) ? 1u : 0u;
+        if (t.pad2) words += tiles;
         if (ev_start && ev_stop)
-            hipExtLaunchKernelGGL(sw_traceback_winmax_kernel, dim3(a->n_pairs), dim3(WAVE * n_waves), (uint32_t)(words * sizeof(uint32_t)), st, ev_start, ev_stop, 0u, *a);
+            hipExtLaunchKernelGGL(sw_traceback_winmax_kernel, dim3(a->n_pairs), dim3(WAVE * n_waves), (uint32_t)(words * sizeof(uint32_t)), st, ev_start, ev_stop, 0u, t);
         else
-            hipLaunchKernelGGL(sw_traceback_winmax_kernel, dim3(a->n_pairs), dim3(WAVE * n_waves), words * sizeof(uint32_t), st, *a);
+            hipLaunchKernelGGL(sw_traceback_winmax_kernel, dim3(a->n_pairs), dim3(WAVE * n_waves), words * sizeof(uint32_t), st, t);
     } else {
         const dim3 grid((a->n_pairs + FILL_WAVES - 1) / FILL_WAVES, SWMI_TB_SLOTS);
         if (a->mode == 0) hipLaunchKernelGGL(sw_traceback_kernel, grid, block, per_wave * FILL_WAVES * sizeof(uint32_t), st, *a);
