@@ -573,6 +573,8 @@ inline uint64_t rec_words(uint32_t n_ops, bool strings) {
 
 }  // namespace
 
+#define SWMI_RES_CELL_CAP 128u            // maximum cells a resident pair lists in LDS (sw_resident_pairs_kernel)
+
 // longest possible traceback of an n x m pair: A + I <= m rows, A + D <= n columns, and -- with match > 0 > gap -- the
 // score match*A + gap*(I + D) must stay positive (`while (score > 0)`), which caps the gap moves
 static uint64_t path_bound(uint64_t n_, uint64_t m_, const swmi_params &p) {
@@ -593,10 +595,12 @@ static uint64_t traceback_lds_bytes(uint32_t mode, uint64_t max_path, uint64_t m
     return 4ull * (tile_words + 4ull * (lds_words + lds_read_words + 96));
 }
 
-// Runs fill + traceback for `work` (already ordered), one chunk, and parses the records.
-// per-pair cell-list geometry: uniform (cap) when cells_cap_exact is empty, else exact per pair.
-static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, size_t hi,
-                     const std::vector<uint64_t> *cells_exact, std::vector<PairOut> &outs) {
+// What a launch of work[lo, hi) needs besides the sequences: pair descriptors with their workspace offsets, the item lists of
+// the kernels that take only some of the pairs (strips of long reads, column chunks, resident pairs, transposed pairs), the
+// window offsets of the split traceback, and the sizes everything downstream is dimensioned by.  Derived on the host, uploaded,
+// and cached in swmi_batch::Prep: a repeated run of the same chunk with the same parameters (bench.py's steps, a Spark job
+// re-running a partition) skips all of it.
+static int prepare_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, size_t hi, const std::vector<uint64_t> *cells_exact) {
     swmi_ctx *ctx = rs.ctx;
     swmi_batch *b = rs.b;
     const size_t np = hi - lo;
@@ -618,7 +622,7 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
     std::vector<uint32_t> tf_items;          // pairs handled whole by sw_tfused_kernel (transposed sweep + traceback)
     size_t n_tf = 0;
     uint32_t tf_max_m = 0, tf_max_n = 0, tf_max_path = 0;
-    const uint32_t res_cell_cap = 128;
+    const uint32_t res_cell_cap = SWMI_RES_CELL_CAP;
     swmi_batch::Prep &pr = b->prep;
     const auto p0 = std::chrono::steady_clock::now();
     const bool prepared = pr.valid && pr.lo == lo && pr.hi == hi && pr.work == (const void *)work.data() && pr.mode == b->eff_mode &&
@@ -817,6 +821,137 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
         pr.tfused_opt = ctx->tfused; pr.n_tf = n_tf; pr.tf_max_m = tf_max_m; pr.tf_max_n = tf_max_n; pr.tf_max_path = tf_max_path;
         pr.col_chunks_opt = ctx->col_chunks; pr.reverse_strips = ctx->dbg_reverse_strips != 0;
     }
+    rs.prep_us += std::chrono::duration<double, std::micro>(p1 - p0).count();
+    rs.prep_upload_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - p1).count();
+    return SWMI_OK;
+}
+
+// SWMI_DEBUG_FILL=1: where the time of the traceback (per-pair ticks, walk / staging shares, the slowest pairs) and of the
+// sweep (ticks, wave placement by HW_ID) went.  Diagnostics only.
+static int dump_traceback_diagnostics(swmi_batch *b, const TraceArgs &ta, size_t np, size_t n_tf) {
+    if (!ta.dbg) return SWMI_OK;
+    std::vector<unsigned long long> d(np * 4);
+    HIP_TRY(hipMemcpy(d.data(), ta.dbg, np * 32, hipMemcpyDeviceToHost));
+    if (n_tf) {          // sw_tfused_kernel's own fields: {ticks, sweep | prologue << 32, replay << 16 | steps, replays | walk << 32}
+        double t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0; unsigned long long mx = 0;
+        for (size_t k = 0; k < np; k++) {
+            t0 += d[4*k]; t1 += d[4*k+1] & 0xFFFFFFFFull; t2 += d[4*k+1] >> 32; t3 += d[4*k+2] >> 16; t4 += d[4*k+3] >> 32; t5 += d[4*k+3] & 0xFFFFFFFFull;
+            mx = std::max(mx, d[4*k]);
+        }
+        fprintf(stderr, "[swmi tfused dbg] ticks per sweeper wavefront: lifetime mean=%.0f max=%llu = prologue %.0f + sweep %.0f + first block task %.0f (%.2f block tasks per wavefront) + waiting for tasks %.0f + rest (more tasks, walk items) %.0f\n",
+                t0 / np, mx, t2 / np, t1 / np, t3 / np, t5 / np, t4 / np, (t0 - t1 - t2 - t3 - t4) / np);
+        {   // the distribution of the wavefront lifetimes and the slowest ones
+            std::vector<size_t> idx(np);
+            for (size_t k = 0; k < np; k++) idx[k] = k;
+            std::sort(idx.begin(), idx.end(), [&](size_t x, size_t y) { return d[4 * x] < d[4 * y]; });
+            auto at = [&](double q) { return d[4 * idx[std::min<size_t>(np - 1, (size_t)(q * np))]]; };
+            fprintf(stderr, "[swmi tfused dbg]   lifetime p10=%llu p50=%llu p90=%llu p99=%llu max=%llu\n", at(0.10), at(0.50), at(0.90), at(0.99), d[4 * idx[np - 1]]);
+            for (size_t t = 0; t < std::min<size_t>(np, 6); t++) {
+                const size_t k = idx[np - 1 - t];
+                fprintf(stderr, "[swmi tfused dbg]   slow wavefront (pair %zu): lifetime %llu, sweep %llu, first block task %llu, block tasks taken %llu, waiting %llu, alignments of its pair %llu\n",
+                        k, d[4 * k], d[4 * k + 1] & 0xFFFFFFFFull, d[4 * k + 2] >> 16, d[4 * k + 3] & 0xFFFFFFFFull, d[4 * k + 3] >> 32,
+                        (unsigned long long)((const PairOut *)((const uint8_t *)b->h_result.p + result_out_off()))[k].n_cells);
+            }
+        }
+    }
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0; unsigned long long mx = 0;
+    double a4 = 0;
+    for (size_t k = 0; k < np; k++) { a0 += d[4*k]; a1 += d[4*k+1] & 0xFFFFFFFFull; a2 += d[4*k+2] & 0xFFFF; a4 += d[4*k+2] >> 16; a3 += d[4*k+3] & 0xFFFFFFFFull; mx = std::max(mx, d[4*k]); }
+    fprintf(stderr, "[swmi tb dbg] wave ticks mean=%.0f max=%llu; walk ticks mean=%.0f; staging ticks mean=%.0f; steps mean=%.1f; iterations mean=%.2f\n",
+            a0 / np, mx, a1 / np, a4 / np, a2 / np, a3 / np);
+    const PairOut *po_dbg = (const PairOut *)((const uint8_t *)b->h_result.p + result_out_off());
+    double cs[4] = {0, 0, 0, 0}, cw[4] = {0, 0, 0, 0}; unsigned long long cm[4] = {0, 0, 0, 0}; size_t cn[4] = {0, 0, 0, 0};
+    for (size_t k = 0; k < np; k++) {
+        const size_t c = std::min<uint64_t>(po_dbg[k].n_cells, 4) - (po_dbg[k].n_cells ? 1 : 0);
+        cs[c] += d[4 * k]; cw[c] += d[4 * k + 1] & 0xFFFFFFFFull; cm[c] = std::max(cm[c], d[4 * k]); cn[c]++;
+    }
+    {   // the slowest pairs: what makes the launch's tail
+        std::vector<size_t> idx(np);
+        for (size_t k = 0; k < np; k++) idx[k] = k;
+        const size_t top = std::min<size_t>(np, 6);
+        std::partial_sort(idx.begin(), idx.begin() + top, idx.end(), [&](size_t x, size_t y) { return d[4 * x] > d[4 * y]; });
+        for (size_t t = 0; t < top; t++)
+            fprintf(stderr, "[swmi tb dbg]   slow pair %zu: ticks=%llu walk=%llu staging=%llu in %llu stagings, steps=%llu iterations=%llu alignments=%llu\n", idx[t],
+                    d[4 * idx[t]], d[4 * idx[t] + 1] & 0xFFFFFFFFull, d[4 * idx[t] + 2] >> 16, d[4 * idx[t] + 3] >> 32, d[4 * idx[t] + 2] & 0xFFFF,
+                    d[4 * idx[t] + 3] & 0xFFFFFFFFull, (unsigned long long)po_dbg[idx[t]].n_cells);
+        for (size_t t = 0; t < top; t++)
+            fprintf(stderr, "[swmi tb dbg]     ... of the staging time of pair %zu, %llu ticks waiting for helpers\n", idx[t], d[4 * idx[t] + 1] >> 32);
+    }
+    for (int c = 0; c < 4; c++)
+        if (cn[c]) fprintf(stderr, "[swmi tb dbg]   %d%s alignment(s): %zu pairs, wave ticks mean=%.0f max=%llu, walk(slot 0) mean=%.0f\n",
+                           c + 1, c == 3 ? "+" : "", cn[c], cs[c] / cn[c], cm[c], cw[c] / cn[c]);
+    return SWMI_OK;
+}
+
+static int dump_fill_diagnostics(swmi_batch *b, const FillArgs &fa, size_t np) {
+    if (!fa.dbg) return SWMI_OK;
+    std::vector<unsigned long long> d(np * 2);
+    HIP_TRY(hipMemcpy(d.data(), fa.dbg, np * 16, hipMemcpyDeviceToHost));
+    unsigned long long ev = 0, cyc = 0, evmax = 0, cmax = 0, cmin = ~0ull;
+    for (size_t k = 0; k < np; k++) {
+        ev += d[2 * k]; cyc += d[2 * k + 1];
+        evmax = std::max(evmax, d[2 * k]); cmax = std::max(cmax, d[2 * k + 1]); cmin = std::min(cmin, d[2 * k + 1]);
+    }
+    fprintf(stderr, "[swmi fill dbg] pairs=%zu slow-path entries mean=%.1f max=%llu; wave ticks mean=%.0f min=%llu max=%llu\n",
+            np, (double)ev / np, evmax, (double)cyc / np, cmin, cmax);
+    if (b->eff_mode == 1) {
+        // the fast sweep stores HW_ID | XCC_ID << 32 instead of an event count: placement of the waves
+        std::unordered_map<unsigned long long, int> per_simd, per_cu;
+        for (size_t k = 0; k < np; k++) {
+            const unsigned long long hw = d[2 * k] & 0xFFFFFFFFull, xcc = (d[2 * k] >> 32) & 0xF;
+            const unsigned long long simd = (hw >> 4) & 3, cu = (hw >> 8) & 15, sh = (hw >> 12) & 1, se = (hw >> 13) & 7;
+            const unsigned long long cukey = (xcc << 16) | (se << 8) | (sh << 4) | cu;
+            per_cu[cukey]++; per_simd[(cukey << 4) | simd]++;
+        }
+        int h_simd[9] = {0}, h_cu[17] = {0};
+        for (auto &kv : per_simd) h_simd[std::min(kv.second, 8)]++;
+        for (auto &kv : per_cu) h_cu[std::min(kv.second, 16)]++;
+        fprintf(stderr, "[swmi fill dbg] placement: %zu CUs, %zu SIMDs used; SIMDs by waves held: 1:%d 2:%d 3:%d 4+:%d; CUs by waves held: 1-4:%d 5-8:%d 9+:%d\n",
+                per_cu.size(), per_simd.size(), h_simd[1], h_simd[2], h_simd[3], h_simd[4] + h_simd[5] + h_simd[6] + h_simd[7] + h_simd[8],
+                h_cu[1] + h_cu[2] + h_cu[3] + h_cu[4], h_cu[5] + h_cu[6] + h_cu[7] + h_cu[8], h_cu[9] + h_cu[10] + h_cu[11] + h_cu[12] + h_cu[13] + h_cu[14] + h_cu[15] + h_cu[16]);
+    }
+    return SWMI_OK;
+}
+
+// The records of a finished launch become part of the batch's results.  The only launch of a run leaves its table and
+// payloads in the pinned block (the batch's own until the next run): indexed there when something asks for an alignment.
+// With several launches in one run each one's records are copied out of the block, which the next launch writes again; the
+// table is dense, so its sequential read also tells how much of the arena is in use.
+static int keep_chunk_records(RunState &rs, const AlnRec *tab, uint64_t n_rec, const uint32_t *arena, uint64_t arena_cap, size_t lo) {
+    swmi_batch *b = rs.b;
+    if (rs.defer_copy && b->raw_chunks.empty()) {
+        b->raw_ext = arena; b->rtab_ext = tab; b->raw_ext_records = n_rec; b->raw_ext_cap = arena_cap;
+        b->raw_chunks.push_back(swmi_batch::RawChunk{0, 0, 0, (size_t)n_rec, lo, {}});
+        return SWMI_OK;
+    }
+    uint64_t used = 0;
+    for (uint64_t k = 0; k < n_rec; k++) {
+        const uint64_t end = (((uint64_t)tab[k].off_hi << 32) | tab[k].off_lo) + rec_words(tab[k].n_ops, b->rec_strings);
+        used = std::max(used, end);
+    }
+    if (used > arena_cap) return fail(SWMI_ERR_HIP, "record payloads overrun the arena");
+    b->raw_chunks.push_back(swmi_batch::RawChunk{b->raw.size(), (size_t)used, b->rtab.size(), (size_t)n_rec, lo, {}});
+    b->raw.insert(b->raw.end(), arena, arena + used);
+    b->rtab.insert(b->rtab.end(), tab, tab + n_rec);
+    return SWMI_OK;
+}
+
+// Runs the kernels for work[lo, hi) -- one launch of each kernel the chunk needs -- waits, and keeps the records; a record arena
+// or table that proves too small is grown to the size the kernels asked for and the traceback repeated.
+// Cell-list geometry: uniform (cell_cap per pair) when cells_exact is null, else exact per pair (the re-run of overflowed pairs).
+static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, size_t hi,
+                     const std::vector<uint64_t> *cells_exact, std::vector<PairOut> &outs) {
+    swmi_ctx *ctx = rs.ctx;
+    swmi_batch *b = rs.b;
+    const size_t np = hi - lo;
+    int rc;
+    if ((rc = prepare_chunk(rs, work, lo, hi, cells_exact))) return rc;
+    const swmi_batch::Prep &pr = b->prep;
+    const uint64_t seam_words = pr.seam_words, n_windows = pr.n_windows;
+    const uint32_t max_path = pr.max_path, max_read = pr.max_read;
+    const size_t n_strip_items = pr.n_strip_items, n_col_items = pr.n_col_items, n_res = pr.n_res, n_tf = pr.n_tf;
+    const uint32_t res_lds_words = pr.res_lds_words, res_ops_words = pr.res_ops_words, res_cell_cap = SWMI_RES_CELL_CAP;
+    const uint32_t tf_max_m = pr.tf_max_m, tf_max_n = pr.tf_max_n, tf_max_path = pr.tf_max_path;
     if (seam_words) HIP_TRY(hipMemsetAsync(b->d_seam.p, 0, seam_words * 4, ctx->stream));
 
     // cell lists
@@ -855,8 +990,6 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
     }
 
     const auto c0 = std::chrono::steady_clock::now();
-    rs.prep_us += std::chrono::duration<double, std::micro>(p1 - p0).count();
-    rs.prep_upload_us += std::chrono::duration<double, std::micro>(c0 - p1).count();
     uint64_t arena_cap = std::max<uint64_t>(np * ctx->arena_words_per_pair, 1024);
     uint64_t tab_cap = std::max<uint64_t>(np * ctx->recs_per_pair_x16 / 16 + 64, 256);
     std::vector<uint8_t> saved_outs;       // PairOut block carried across an arena re-allocation
@@ -1081,85 +1214,8 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
             HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[ext_timing ? 2 : 1], ctx->ev[3])); rs.tb_ms += ms;
             if (!zc) { HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4])); rs.d2h_ms += ms; }
         }
-        if (ta.dbg) {
-            std::vector<unsigned long long> d(np * 4);
-            HIP_TRY(hipMemcpy(d.data(), ta.dbg, np * 32, hipMemcpyDeviceToHost));
-            if (n_tf) {          // sw_tfused_kernel's own fields: {ticks, sweep | prologue << 32, replay << 16 | steps, replays | walk << 32}
-                double t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0; unsigned long long mx = 0;
-                for (size_t k = 0; k < np; k++) {
-                    t0 += d[4*k]; t1 += d[4*k+1] & 0xFFFFFFFFull; t2 += d[4*k+1] >> 32; t3 += d[4*k+2] >> 16; t4 += d[4*k+3] >> 32; t5 += d[4*k+3] & 0xFFFFFFFFull;
-                    mx = std::max(mx, d[4*k]);
-                }
-                fprintf(stderr, "[swmi tfused dbg] ticks per sweeper wavefront: lifetime mean=%.0f max=%llu = prologue %.0f + sweep %.0f + first block task %.0f (%.2f block tasks per wavefront) + waiting for tasks %.0f + rest (more tasks, walk items) %.0f\n",
-                        t0 / np, mx, t2 / np, t1 / np, t3 / np, t5 / np, t4 / np, (t0 - t1 - t2 - t3 - t4) / np);
-                {   // the distribution of the wavefront lifetimes and the slowest ones
-                    std::vector<size_t> idx(np);
-                    for (size_t k = 0; k < np; k++) idx[k] = k;
-                    std::sort(idx.begin(), idx.end(), [&](size_t x, size_t y) { return d[4 * x] < d[4 * y]; });
-                    auto at = [&](double q) { return d[4 * idx[std::min<size_t>(np - 1, (size_t)(q * np))]]; };
-                    fprintf(stderr, "[swmi tfused dbg]   lifetime p10=%llu p50=%llu p90=%llu p99=%llu max=%llu\n", at(0.10), at(0.50), at(0.90), at(0.99), d[4 * idx[np - 1]]);
-                    for (size_t t = 0; t < std::min<size_t>(np, 6); t++) {
-                        const size_t k = idx[np - 1 - t];
-                        fprintf(stderr, "[swmi tfused dbg]   slow wavefront (pair %zu): lifetime %llu, sweep %llu, first block task %llu, block tasks taken %llu, waiting %llu, alignments of its pair %llu\n",
-                                k, d[4 * k], d[4 * k + 1] & 0xFFFFFFFFull, d[4 * k + 2] >> 16, d[4 * k + 3] & 0xFFFFFFFFull, d[4 * k + 3] >> 32,
-                                (unsigned long long)((const PairOut *)((const uint8_t *)b->h_result.p + result_out_off()))[k].n_cells);
-                    }
-                }
-            }
-            double a0 = 0, a1 = 0, a2 = 0, a3 = 0; unsigned long long mx = 0;
-            double a4 = 0;
-            for (size_t k = 0; k < np; k++) { a0 += d[4*k]; a1 += d[4*k+1] & 0xFFFFFFFFull; a2 += d[4*k+2] & 0xFFFF; a4 += d[4*k+2] >> 16; a3 += d[4*k+3] & 0xFFFFFFFFull; mx = std::max(mx, d[4*k]); }
-            fprintf(stderr, "[swmi tb dbg] wave ticks mean=%.0f max=%llu; walk ticks mean=%.0f; staging ticks mean=%.0f; steps mean=%.1f; iterations mean=%.2f\n",
-                    a0 / np, mx, a1 / np, a4 / np, a2 / np, a3 / np);
-            const PairOut *po_dbg = (const PairOut *)((const uint8_t *)b->h_result.p + result_out_off());
-            double cs[4] = {0, 0, 0, 0}, cw[4] = {0, 0, 0, 0}; unsigned long long cm[4] = {0, 0, 0, 0}; size_t cn[4] = {0, 0, 0, 0};
-            for (size_t k = 0; k < np; k++) {
-                const size_t c = std::min<uint64_t>(po_dbg[k].n_cells, 4) - (po_dbg[k].n_cells ? 1 : 0);
-                cs[c] += d[4 * k]; cw[c] += d[4 * k + 1] & 0xFFFFFFFFull; cm[c] = std::max(cm[c], d[4 * k]); cn[c]++;
-            }
-            {   // the slowest pairs: what makes the launch's tail
-                std::vector<size_t> idx(np);
-                for (size_t k = 0; k < np; k++) idx[k] = k;
-                const size_t top = std::min<size_t>(np, 6);
-                std::partial_sort(idx.begin(), idx.begin() + top, idx.end(), [&](size_t x, size_t y) { return d[4 * x] > d[4 * y]; });
-                for (size_t t = 0; t < top; t++)
-                    fprintf(stderr, "[swmi tb dbg]   slow pair %zu: ticks=%llu walk=%llu staging=%llu in %llu stagings, steps=%llu iterations=%llu alignments=%llu\n", idx[t],
-                            d[4 * idx[t]], d[4 * idx[t] + 1] & 0xFFFFFFFFull, d[4 * idx[t] + 2] >> 16, d[4 * idx[t] + 3] >> 32, d[4 * idx[t] + 2] & 0xFFFF,
-                            d[4 * idx[t] + 3] & 0xFFFFFFFFull, (unsigned long long)po_dbg[idx[t]].n_cells);
-                for (size_t t = 0; t < top; t++)
-                    fprintf(stderr, "[swmi tb dbg]     ... of the staging time of pair %zu, %llu ticks waiting for helpers\n", idx[t], d[4 * idx[t] + 1] >> 32);
-            }
-            for (int c = 0; c < 4; c++)
-                if (cn[c]) fprintf(stderr, "[swmi tb dbg]   %d%s alignment(s): %zu pairs, wave ticks mean=%.0f max=%llu, walk(slot 0) mean=%.0f\n",
-                                   c + 1, c == 3 ? "+" : "", cn[c], cs[c] / cn[c], cm[c], cw[c] / cn[c]);
-        }
-        if (fa.dbg && attempt == 0) {
-            std::vector<unsigned long long> d(np * 2);
-            HIP_TRY(hipMemcpy(d.data(), fa.dbg, np * 16, hipMemcpyDeviceToHost));
-            unsigned long long ev = 0, cyc = 0, evmax = 0, cmax = 0, cmin = ~0ull;
-            for (size_t k = 0; k < np; k++) {
-                ev += d[2 * k]; cyc += d[2 * k + 1];
-                evmax = std::max(evmax, d[2 * k]); cmax = std::max(cmax, d[2 * k + 1]); cmin = std::min(cmin, d[2 * k + 1]);
-            }
-            fprintf(stderr, "[swmi fill dbg] pairs=%zu slow-path entries mean=%.1f max=%llu; wave ticks mean=%.0f min=%llu max=%llu\n",
-                    np, (double)ev / np, evmax, (double)cyc / np, cmin, cmax);
-            if (b->eff_mode == 1) {
-                // the fast sweep stores HW_ID | XCC_ID << 32 instead of an event count: placement of the waves
-                std::unordered_map<unsigned long long, int> per_simd, per_cu;
-                for (size_t k = 0; k < np; k++) {
-                    const unsigned long long hw = d[2 * k] & 0xFFFFFFFFull, xcc = (d[2 * k] >> 32) & 0xF;
-                    const unsigned long long simd = (hw >> 4) & 3, cu = (hw >> 8) & 15, sh = (hw >> 12) & 1, se = (hw >> 13) & 7;
-                    const unsigned long long cukey = (xcc << 16) | (se << 8) | (sh << 4) | cu;
-                    per_cu[cukey]++; per_simd[(cukey << 4) | simd]++;
-                }
-                int h_simd[9] = {0}, h_cu[17] = {0};
-                for (auto &kv : per_simd) h_simd[std::min(kv.second, 8)]++;
-                for (auto &kv : per_cu) h_cu[std::min(kv.second, 16)]++;
-                fprintf(stderr, "[swmi fill dbg] placement: %zu CUs, %zu SIMDs used; SIMDs by waves held: 1:%d 2:%d 3:%d 4+:%d; CUs by waves held: 1-4:%d 5-8:%d 9+:%d\n",
-                        per_cu.size(), per_simd.size(), h_simd[1], h_simd[2], h_simd[3], h_simd[4] + h_simd[5] + h_simd[6] + h_simd[7] + h_simd[8],
-                        h_cu[1] + h_cu[2] + h_cu[3] + h_cu[4], h_cu[5] + h_cu[6] + h_cu[7] + h_cu[8], h_cu[9] + h_cu[10] + h_cu[11] + h_cu[12] + h_cu[13] + h_cu[14] + h_cu[15] + h_cu[16]);
-            }
-        }
+        if ((rc = dump_traceback_diagnostics(b, ta, np, n_tf))) return rc;
+        if (attempt == 0 && (rc = dump_fill_diagnostics(b, fa, np))) return rc;
         const uint8_t *h = (const uint8_t *)b->h_result.p;
         ArenaHdr hdr_copy{};
         const ArenaHdr *hdr = (const ArenaHdr *)h;
@@ -1220,27 +1276,10 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
             ctx->arena_copy_wpp = hdr_words * 5 / (4 * np) + 2;
             ctx->recs_per_pair_x16 = std::max<uint64_t>(ctx->recs_per_pair_x16, n_rec * 20 / np + 1);
         }
-        if (!rs.keep) return SWMI_OK;
-        if (rs.defer_copy && b->raw_chunks.empty()) {
-            // the only launch of the run: table and payloads stay in the pinned block (the batch's own until the next run)
-            // and are indexed there when something asks for an alignment
-            b->raw_ext = aw; b->rtab_ext = tab; b->raw_ext_records = n_rec; b->raw_ext_cap = arena_cap;
-            b->raw_chunks.push_back(swmi_batch::RawChunk{0, 0, 0, (size_t)n_rec, lo, {}});
+        if (rs.keep) {
+            if ((rc = keep_chunk_records(rs, tab, n_rec, aw, arena_cap, lo))) return rc;
             rs.copyout_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - c2).count();
-            return SWMI_OK;
         }
-        // several launches in one run: each one's table and payloads are copied out of the pinned block, which the next
-        // launch writes again.  The table is dense: its sequential read also tells how much of the arena is in use.
-        uint64_t used = 0;
-        for (uint64_t k = 0; k < n_rec; k++) {
-            const uint64_t end = (((uint64_t)tab[k].off_hi << 32) | tab[k].off_lo) + rec_words(tab[k].n_ops, b->rec_strings);
-            used = std::max(used, end);
-        }
-        if (used > arena_cap) return fail(SWMI_ERR_HIP, "record payloads overrun the arena");
-        b->raw_chunks.push_back(swmi_batch::RawChunk{b->raw.size(), (size_t)used, b->rtab.size(), (size_t)n_rec, lo, {}});
-        b->raw.insert(b->raw.end(), aw, aw + used);
-        b->rtab.insert(b->rtab.end(), tab, tab + n_rec);
-        rs.copyout_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - c2).count();
         return SWMI_OK;
     }
 }
