@@ -162,7 +162,7 @@ struct HostAln {
     uint32_t rank;
     int32_t begin, end_i, end_j;
     uint32_t n_ops;
-    const uint32_t *rec = nullptr;   // the alignment's payload in the arena: packed ops [, the two strings written by the kernels]
+    const uint32_t *rec = nullptr;   // the alignment's payload in the arena: the two strings written by the kernels, or the packed ops
     int64_t str_id = -1;    // records without strings: >= 0 once the strings are built, offset of the reference-side string in swmi_batch::str_buf
 };
 
@@ -566,9 +566,9 @@ inline size_t result_out_off() { return 64; }
 // layout of the result block: [ArenaHdr | PairOut x np | record table, tab_cap entries | arena words ...]
 inline size_t result_tab_off(size_t np) { return (64 + np * sizeof(PairOut) + 255) & ~(size_t)255; }
 inline size_t result_arena_off(size_t np, uint64_t tab_cap) { return (result_tab_off(np) + tab_cap * sizeof(AlnRec) + 255) & ~(size_t)255; }
-// dwords of one alignment's payload: ops packed 16 per dword [+ the two strings, n_ops / 4 + 1 dwords each (swmi_emit.h)]
+// dwords of one alignment's payload: the two strings, n_ops / 4 + 1 dwords each, or the ops packed 16 per dword (swmi_emit.h)
 inline uint64_t rec_words(uint32_t n_ops, bool strings) {
-    return ((uint64_t)n_ops + 15) / 16 + (strings ? 2 * ((uint64_t)n_ops / 4 + 1) : 0);
+    return strings ? 2 * ((uint64_t)n_ops / 4 + 1) : ((uint64_t)n_ops + 15) / 16;
 }
 
 }  // namespace
@@ -689,10 +689,6 @@ static int prepare_chunk(RunState &rs, const std::vector<Work> &work, size_t lo,
         d.ref_id = w.pair / n_reads;
         d.read_id = w.pair % n_reads;
         d.out_id = (uint32_t)k;
-        d.dir_off = dir_words;
-        d.seam_off = seam_words;
-        dir_words += w.dir_words;
-        seam_words += w.seam_words;
         const uint32_t m_ = b->read_desc[d.read_id].len, n_ = b->ref_desc[d.ref_id].len;
         if (b->eff_mode == 1) {
             const uint64_t rps = 64ull * swmi_rows_per_lane(m_);
@@ -770,6 +766,17 @@ static int prepare_chunk(RunState &rs, const std::vector<Work> &work, size_t lo,
         for (uint32_t k : res_items) pd[k].pad = 0;
         res_items.clear();
         n_res = 0; res_lds_words = 0; res_ops_words = 0;
+    }
+    // workspace offsets, now that every pair's kernel is known: a resident pair keeps everything in LDS and gets none
+    // (40,000 pairs of 80 x 400 were charged 0.6 GB of checkpoints nobody writes)
+    {
+        std::vector<uint8_t> is_res(np, 0);
+        for (uint32_t k : res_items) is_res[k] = 1;
+        for (size_t k = 0; k < np; k++) {
+            pd[k].dir_off = dir_words;
+            pd[k].seam_off = seam_words;
+            if (!is_res[k]) { dir_words += work[lo + k].dir_words; seam_words += work[lo + k].seam_words; }
+        }
     }
     if (b->eff_mode == 1) win_off[np] = (uint32_t)std::min<uint64_t>(n_windows, 0xFFFFFFFFu);
     }
@@ -1816,7 +1823,7 @@ extern "C" int swmi_pair_alignment(swmi_batch *b, uint64_t pair, uint64_t k,
     if (len) *len = a.n_ops;
     if (b->rec_strings) {
         // both strings were written by the traceback kernel right behind the record (swmi_emit.h): pointers only
-        const uint32_t *sr = a.rec + (a.n_ops + 15u) / 16u;
+        const uint32_t *sr = a.rec;
         if (ref_aln) *ref_aln = (const char *)sr;
         if (read_aln) *read_aln = (const char *)(sr + a.n_ops / 4u + 1u);
         return SWMI_OK;
@@ -1984,7 +1991,7 @@ extern "C" int swmi_ref_sites_packed(swmi_batch *b, uint32_t ref_lo, uint32_t re
                 HostAln &a = b->alns[pr.first + sr.k];
                 const char *ra, *qa;
                 if (b->rec_strings) {
-                    const uint32_t *w = a.rec + (a.n_ops + 15u) / 16u;
+                    const uint32_t *w = a.rec;
                     ra = (const char *)w; qa = (const char *)(w + a.n_ops / 4u + 1u);
                 } else {
                     if (a.str_id < 0) materialise(b, sr.pair, a, pr.first + sr.k);

@@ -19,7 +19,7 @@
 //   cells  uint2[]    per pair, up to cell_cap (i, j) coordinates of the tied maximum cells.
 //   out    PairOut[]  per pair score / count / flags.
 //   rec_tab AlnRec[]  one entry per alignment, in the order the traceback kernels reserved them;
-//   arena  uint32[]   the alignments' variable-length payloads (packed ops, the two aligned strings).
+//   arena  uint32[]   the alignments' variable-length payloads (the two aligned strings, or the packed ops).
 #pragma once
 #include <stdint.h>
 
@@ -85,9 +85,9 @@ struct PairOut {
 };
 
 // One alignment = one entry of the RECORD TABLE (dense, 8 dwords each, in the order the records were reserved) + its payload
-// in the arena: ceil(n_ops/16) dwords of 2-bit ops (op t of the traceback, first = the max cell, at bits 2*(t%16) of dword
-// t/16) and -- when TraceArgs.raw is set -- the two aligned strings GetAlignment returns (SmithWaterman.java:418-431):
-// refAligned then readAligned, n_ops/4 + 1 dwords each (NUL-terminated, NUL-padded).  The table is what the host indexes: a
+// in the arena.  With TraceArgs.raw set: the two aligned strings GetAlignment returns (SmithWaterman.java:418-431), refAligned
+// then readAligned, n_ops/4 + 1 dwords each (NUL-terminated, NUL-padded).  Otherwise: ceil(n_ops/16) dwords of 2-bit ops (op t
+// of the traceback, first = the max cell, at bits 2*(t%16) of dword t/16), from which the host builds the strings on demand.  The table is what the host indexes: a
 // dense array reads at memory bandwidth, where headers scattered through the arena were one dependent cache miss per record
 // (0.11 ms per 1161 records of a pinned block the GPU had just written).
 struct AlnRec {

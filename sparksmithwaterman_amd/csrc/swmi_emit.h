@@ -1,5 +1,5 @@
 // swmi_emit.h -- device side of GetAlignment's output (src/sw/SmithWaterman.java:388-406, 418-431): the two aligned strings
-// of one alignment, written by a whole wavefront behind the alignment's packed ops in the arena (swmi_device.h: AlnRec).
+// of one alignment, written by a whole wavefront into the alignment's payload in the arena (swmi_device.h: AlnRec).
 //
 // The walk leaves the ops of a path from the maximum cell backwards (op 0 = the maximum cell).  The reference pushes one
 // {refChar, readChar} pair per step on a stack and pops it into the strings, so character p of both strings belongs to op
@@ -31,9 +31,9 @@ struct SwmiOpsPacked {                    // ops packed 16 per dword, op t at bi
 // dwords of ONE string of an alignment of n_ops steps (characters + NUL, padded)
 SWMI_HD static inline uint32_t swmi_str_words(uint32_t n_ops) { return n_ops / 4u + 1u; }
 
-// dwords of an alignment's payload in the arena: packed ops [+ both strings]
+// dwords of an alignment's payload in the arena: both strings, or -- records without strings -- the packed ops
 SWMI_HD static inline uint32_t swmi_payload_words(uint32_t n_ops, bool strings) {
-    return (n_ops + 15u) / 16u + (strings ? 2u * swmi_str_words(n_ops) : 0u);
+    return strings ? 2u * swmi_str_words(n_ops) : (n_ops + 15u) / 16u;
 }
 
 // Lane 0 reserves `words` dwords of arena and `n_rec` table entries with ONE atomic (swmi_device.h: ArenaHdr).  Two halves,
@@ -88,6 +88,10 @@ struct SwmiStrings {
         uint32_t cr[4], cq[4];
 #pragma unroll
         for (uint32_t q = 4u; q-- > 0u;) {
+            cr[q] = 0u; cq[q] = 0u;
+            // (a pass none of whose characters lands in a stored dword -- the strings end at n_ops, their padding before
+            //  n_ops + 4 -- is skipped: two of the four passes for the 80-step alignments of the EngineerData shapes)
+            if (256u * c + 64u * q >= n_ops + 4u) continue;
             const uint32_t p = 256u * c + 64u * q + 63u - lane;
             const bool valid = p < n_ops;
             const uint32_t op = valid ? ops(n_ops - 1u - p) : 3u;
@@ -104,6 +108,7 @@ struct SwmiStrings {
         }
 #pragma unroll
         for (uint32_t q = 0; q < 4u; ++q) {
+            if (256u * c + 64u * q >= n_ops + 4u) continue;
             sr[64u * q + 63u - lane] = (uint8_t)cr[q];
             sq[64u * q + 63u - lane] = (uint8_t)cq[q];
         }

@@ -53,8 +53,22 @@ __device__ __forceinline__ int wave_shr1_zero(int src) {
     return __builtin_amdgcn_update_dpp(0, src, 0x138 /*wave_shr:1*/, 0xf, 0xf, true);
 }
 
-// wave-wide signed max through the DPP network (no LDS): 4 row steps, 2 row broadcasts, result read from lane 63
+// wave-wide signed max through the DPP network (no LDS): 4 row steps, 2 row broadcasts, result read from lane 63.
+// The DPP modifier sits on the v_max itself (a lane without a source lane, or outside the row mask, is simply not written: it
+// keeps its value, which is what max(v, v) gave before): 6 VALU + the wait states a DPP read of a just-written register
+// needs, where `update_dpp` + max compiled to a copy, a v_mov_b32_dpp and a v_max per step -- 24 instructions per window
+// close of the sweep, 0.4 per anti-diagonal step.
 __device__ __forceinline__ int wave_max_i32(int v) {
+#ifndef SWMI_NO_ASM
+    asm volatile("s_nop 1\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"      // lane 15 of every row holds the row's max
+                 "v_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"   // into rows 1 and 3
+                 "v_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"         // into rows 2 and 3: lane 63 holds the wave's max
+                 : "+v"(v));
+#else
 #define SWMI_DPP_MAX(ctrl, rmask)                                                          \
     { int o_ = __builtin_amdgcn_update_dpp(v, v, ctrl, rmask, 0xf, false); v = v > o_ ? v : o_; }
     SWMI_DPP_MAX(0x111, 0xf)   // row_shr:1
@@ -64,6 +78,7 @@ __device__ __forceinline__ int wave_max_i32(int v) {
     SWMI_DPP_MAX(0x142, 0xa)   // row_bcast:15 into rows 1 and 3
     SWMI_DPP_MAX(0x143, 0xc)   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's max
 #undef SWMI_DPP_MAX
+#endif
     return __builtin_amdgcn_readlane(v, 63);
 }
 
@@ -1437,7 +1452,7 @@ __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDes
             WAVE_SYNC();
 
             // ---- the record: a table entry + the payload (ops packed 2 bits each, 16 per dword [+ the two aligned strings]) ----
-            const uint32_t opw = (n_ops + 15u) / 16u;
+            const uint32_t opw = A.raw ? 0u : (n_ops + 15u) / 16u;          // (records with strings carry no ops)
             const uint32_t words = swmi_payload_words(n_ops, A.raw != nullptr);
             const SwmiReserve rsv = swmi_reserve_issue(A, lane, words, 1u);
             // while the reservation is on its way: this lane's first dword of packed ops, and the last 256 characters of
@@ -1470,8 +1485,8 @@ __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDes
                 for (uint32_t w = lane + WAVE; w < opw; w += WAVE) dst[w] = pack16(w);
                 if (A.raw) {
                     const uint32_t w = 64u * (ctop - 1u) + lane;
-                    if (w < sw) { dst[opw + w] = wr0; dst[opw + sw + w] = wq0; }
-                    strs.store_from(dst + opw, ctop - 1u);
+                    if (w < sw) { dst[w] = wr0; dst[sw + w] = wq0; }
+                    strs.store_from(dst, ctop - 1u);
                 }
             } else if (lane == 0) {
                 atomicOr(&A.out[pd.out_id].flags, SWMI_F_ARENA_OVF);
@@ -2073,7 +2088,7 @@ __device__ __forceinline__ void resident_pair(const TraceArgs &A, const Resident
         if ((nops & 15u) != 0u && nops <= max_ops) my_ops[nops >> 4] = cur;
         WAVE_SYNC();
         // records: table entries + payloads (packed ops [+ strings]), contiguous for the whole wave
-        const uint32_t opw = (nops + 15u) / 16u;
+        const uint32_t opw = A.raw ? 0u : (nops + 15u) / 16u;                // (records with strings carry no ops)
         const uint32_t words = mine ? swmi_payload_words(nops, A.raw != nullptr) : 0u;
         const uint32_t incl = wave_scan_add_u32(words);
         const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
@@ -2097,7 +2112,7 @@ __device__ __forceinline__ void resident_pair(const TraceArgs &A, const Resident
                     const uint32_t at = (uint32_t)__builtin_amdgcn_readlane((int)(incl - words), (int)a);
                     const uint32_t ai = (uint32_t)__builtin_amdgcn_readlane((int)c0.x, (int)a);
                     const uint32_t aj = (uint32_t)__builtin_amdgcn_readlane((int)c0.y, (int)a);
-                    swmi_emit_strings(A.arena + off + at + (na + 15u) / 16u, SwmiOpsPacked{opsb + a * X.res_ops_words},
+                    swmi_emit_strings(A.arena + off + at, SwmiOpsPacked{opsb + a * X.res_ops_words},
                                       na, ai, aj, raw_ref, raw_read, lane, scratch);
                 }
             }

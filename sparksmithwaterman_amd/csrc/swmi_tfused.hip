@@ -411,7 +411,7 @@ __device__ __forceinline__ bool tf_walk(const TraceArgs &A, const TFusedArgs &X,
     if (foreign >= 0 && lane == 0) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); tf_lds_add(&sh->tile_users[foreign], 0xFFFFFFFFu); }
     WAVE_SYNC();
     // the record: a table entry + the payload -- the staged ops (one per byte) packed 16 per dword [+ the two strings]
-    const uint32_t opw = (nops + 15u) / 16u, words = swmi_payload_words(nops, A.raw != nullptr);
+    const uint32_t opw = A.raw ? 0u : (nops + 15u) / 16u, words = swmi_payload_words(nops, A.raw != nullptr);      // (strings, or ops)
     unsigned long long off;
     uint32_t rslot;
     if (swmi_reserve(A, lane, words, 1u, off, rslot) && !bad && nops <= stage_cap) {
@@ -429,7 +429,7 @@ __device__ __forceinline__ bool tf_walk(const TraceArgs &A, const TFusedArgs &X,
             dst[w] = v;
         }
         if (A.raw)                                                        // the two strings GetAlignment returns (SmithWaterman.java:418-431)
-            swmi_emit_strings(dst + opw, SwmiOpsPerByte{stage_b}, nops, ci, cj, P.raw_ref, P.raw_read, lane,
+            swmi_emit_strings(dst, SwmiOpsPerByte{stage_b}, nops, ci, cj, P.raw_ref, P.raw_read, lane,
                               R.stage + (X.stage_words - SWMI_EMIT_SCRATCH_WORDS));
     } else if (lane == 0) {
         atomicOr(&A.out[out_id].flags, SWMI_F_ARENA_OVF);

@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--mode", type=int, default=-1, help="pipeline: -1 automatic (default), 0, 1, 2")
     ap.add_argument("--col-chunks", type=int, default=0, help="0 automatic, 1 never, N force")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="any swmi_set_option knob (A/B runs), e.g. device_strings=0")
+    ap.add_argument("--only", default="1,2,3,4", help="which of the four sweeps to run")
     args = ap.parse_args()
     import sparksmithwaterman_amd as sw
     from oracle import sw_oracle as orc
@@ -30,7 +32,11 @@ def main():
     ctx = sw.Context(0)
     ctx.set_option("mode", args.mode)
     ctx.set_option("col_chunks", args.col_chunks)
-    print("pipeline option: mode %d, col_chunks %d" % (args.mode, args.col_chunks))
+    for kv in args.opt:
+        name, _, value = kv.partition("=")
+        ctx.set_option(name, int(value))
+    print("pipeline option: mode %d, col_chunks %d%s" % (args.mode, args.col_chunks, "".join(", " + kv for kv in args.opt)))
+    only = set(args.only.split(","))
     modes = []
 
     def run(refs, reads, check):
@@ -64,18 +70,22 @@ def main():
     q = args.quick
     # test 1: number of reads (80 bp) against one 400 bp reference      EngineerData.java:51-79
     pts = [20, 50, 100, 200] if q else [20, 50, 100, 200, 400, 800, 1600]
-    table("reads sweep: N reads x 80 bp vs 1 ref x 400 bp", [(str(n), run([REF * 5], [READ_80] * n, n <= 200)) for n in pts])
+    if "1" in only:
+      table("reads sweep: N reads x 80 bp vs 1 ref x 400 bp", [(str(n), run([REF * 5], [READ_80] * n, n <= 200)) for n in pts])
     # test 2: read length, 5 reads                                       EngineerData.java:87-104
     pts = [20, 100, 300] if q else [20, 40, 80, 100, 200, 300, 400, 500]
-    table("read-length sweep: 5 reads x L vs 1 ref x 4000 bp",
+    if "2" in only:
+      table("read-length sweep: 5 reads x L vs 1 ref x 4000 bp",
           [(str(L), run([REF * 50], [(READ_80 * 7)[:L]] * 5, L <= 200)) for L in pts])
     # test 3: number of references (400 bp), one 80 bp read              EngineerData.java:116-169
     pts = [1, 100, 1000] if q else [1, 10, 100, 1000, 4000, 10000, 40000]
-    table("#references sweep: 1 read x 80 bp vs N refs x 400 bp",
+    if "3" in only:
+      table("#references sweep: 1 read x 80 bp vs N refs x 400 bp",
           [(str(n), run([REF * 5] * n, [READ_80], n <= 1000)) for n in pts])
     # test 4: reference length, one reference, one 80 bp read            EngineerData.java:178-224
     pts = [80, 1600, 16000] if q else [80, 400, 1600, 8000, 32000, 128000]
-    table("reference-length sweep: 1 read x 80 bp vs 1 ref x L",
+    if "4" in only:
+      table("reference-length sweep: 1 read x 80 bp vs 1 ref x L",
           [(str(L), run([REF * (L // 80)], [READ_80], L <= 8000)) for L in pts])
     ctx.close()
 
