@@ -24,6 +24,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+EVENT_EVERY = 4         # the timed steps whose sweep kernel is bracketed by HIP events: every 4th (bench.py: timed loop)
 
 WORKLOAD_OF_MODE = {
     1: "score-only sweep (lane-state checkpoints + one maximum per 32-step window) + traceback by window re-sweep "
@@ -176,7 +177,10 @@ def main():
     bytes_rank = sum(alg_bytes(m, len(r)) for r in refs)
 
     ctx = sw.Context(local_rank)
-    ctx.set_option("profiling", 1)
+    # HIP events around the SWEEP of every timed step (roofline.achieved needs that kernel's duration live, inside the timed
+    # region); the traceback's duration is measured with the full set of events in a separate, labelled loop outside it --
+    # every marker packet costs the step ~3.5 us (profiles/r03/host_breakdown_headline.txt)
+    ctx.set_option("profiling", 2)
     if args.mode is not None:
         ctx.set_option("mode", args.mode)
     if args.col_chunks is not None:
@@ -242,13 +246,19 @@ def main():
         step()
     drain()
     sync()
-    fill_ms = tb_ms = d2h_ms = 0.0
-    launches = 0
+    fill_ms = 0.0
+    launches = timed_steps = 0
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for k in range(args.steps):
+        # the sweep kernel is bracketed by HIP events on every EVENT_EVERY-th step of the timed region (the two marker packets
+        # cost a step 8 us, 5 % of it: profiles/r03/host_breakdown_headline.txt); its average duration over those launches is what
+        # roofline.achieved divides by, and rocprofv3's kernel trace of the same command must agree (profiles/)
+        sampled = k % EVENT_EVERY == 0
+        ctx.set_option("profiling", 2 if sampled else 0)
         step()
-        t = batch.timing()
-        fill_ms += t.fill_ms; tb_ms += t.traceback_ms; d2h_ms += t.d2h_ms; launches += t.fill_launches
+        if sampled:
+            t = batch.timing()
+            fill_ms += t.fill_ms; launches += t.fill_launches; timed_steps += 1
     last = drain()
     sync()
     elapsed = time.perf_counter() - t0
@@ -271,14 +281,15 @@ def main():
         reduce_ms = (time.perf_counter() - r0) / 20 * 1e3
     # (b) a second, labelled figure: the step INCLUDING what OptAlignments hands back -- record index + every string
     mat_steps = max(3, min(args.steps, 20))
+    ctx.set_option("profiling", 0)
     sync()
     m0 = time.perf_counter()
     for _ in range(mat_steps):
         batch.run(params)
         n_aln_all, n_chars = batch.materialise_all()
     ms_mat = (time.perf_counter() - m0) / mat_steps * 1e3
-    # (c) a third: the same steps without the three HIP events per run the roofline figures need (option "profiling" off, the
-    # library's default): what a caller that does not time the kernels pays
+    # (c) a third: the same steps without any HIP events (the timed steps carry the two around the sweep that the roofline
+    # figure needs) -- option "profiling" off, the library's default: what a caller that does not time the kernels pays
     ctx.set_option("profiling", 0)
     for _ in range(3):
         batch.run(params)
@@ -288,7 +299,16 @@ def main():
         batch.run(params)
     sync()
     ms_noev = (time.perf_counter() - e0) / args.steps * 1e3
+    # (d) the traceback kernel's duration: the same steps with every stage bracketed by events, outside the timed region
     ctx.set_option("profiling", 1)
+    tb_steps = max(5, min(args.steps, 20))
+    tb_ms = d2h_ms = 0.0
+    for _ in range(tb_steps):
+        batch.run(params)
+        t = batch.timing()
+        tb_ms += t.traceback_ms; d2h_ms += t.d2h_ms
+    tb_ms *= args.steps / tb_steps; d2h_ms *= args.steps / tb_steps        # (reported per step below, like the sweep's)
+    ctx.set_option("profiling", 2)
     gpu_scores, gpu_naln = batch.pair_results()
     winner = int(np.argmax(batch.ref_totals()))
 
@@ -328,8 +348,9 @@ def main():
             "alignments_per_s": round(len(refs) * len(reads) * world * args.steps / elapsed, 1),
             "ms_per_step_materialised": round(ms_mat, 4),
             "ms_per_step_without_events": round(ms_noev, 4),
-            "materialised": {"what": "run + record index + both strings of every alignment (swmi_batch_materialise_all), "
-                                     "rank 0, outside the timed region", "steps": mat_steps,
+            "materialised": {"what": "run (both aligned strings of every alignment are written by the traceback kernels) + the index over "
+                                     "every alignment (swmi_batch_materialise_all): everything OptAlignments returns; rank 0, no events, "
+                                     "outside the timed region", "steps": mat_steps,
                              "alignments": int(n_aln_all), "chars": int(n_chars),
                              "gcups": round(cells_rank / (ms_mat * 1e-3) / 1e9, 3)},
             "config": {"workload": "configs[1]: 1 read x %d bp vs %d refs x %d bp per GPU, scores 5/-3/-4, mode %d: %s"
@@ -342,7 +363,11 @@ def main():
                          "kernel": kernel_name, "kernel_avg_ms": round(fill_avg_s * 1e3, 4),
                          "alg_bytes_per_launch": bytes_rank,
                          "kernel_gcups": round(cells_rank / fill_avg_s / 1e9, 2) if fill_avg_s > 0 else None,
-                         "traceback_avg_ms": round(tb_ms / args.steps, 4), "d2h_avg_ms": round(d2h_ms / args.steps, 4)},
+                         "traceback_avg_ms": round(tb_ms / args.steps, 4), "d2h_avg_ms": round(d2h_ms / args.steps, 4),
+                         "kernel_timed_launches": launches,
+                         "kernel_timing": "HIP events on the library's stream around the sweep kernel of every %d-th timed step (%d of %d steps)" % (EVENT_EVERY, timed_steps, args.steps),
+                         "traceback_note": "measured in %d extra steps with every stage bracketed by events, outside the timed region "
+                                           "(the timed steps bracket the sweep only)" % tb_steps},
             "check": {"winner_ref": winner, "winner_total": batch.ref_total(winner)},
         }
         if reduce_ms is not None:
@@ -391,7 +416,7 @@ def strong_scaling(args, world, rank, local_rank, one_gpu, dev):
     bytes_rank = sum(int(c) * alg_bytes(int(mq), int(n)) for n in lengths[local_ids] for mq, c in zip(read_lens, read_cnt))
 
     ctx = sw.Context(local_rank)
-    ctx.set_option("profiling", 1)
+    ctx.set_option("profiling", 1)          # (every stage: a chunk runs for tens of milliseconds, the marker packets do not matter)
     ctx.set_option("stream_keep_records", 0)
     for kv in args.opt:
         name, _, value = kv.partition("=")

@@ -78,7 +78,8 @@ void        swmi_default_params(swmi_params *p);
 /* Tuning knobs (all optional).  cell_cap: tied-maximum cells kept per pair in the
  * fast path (pairs with more are re-run on the GPU with an exact-size list);
  * max_workspace_bytes: cap on the per-batch workspace arena (larger batches are run in
- * chunks); profiling != 0 brackets every kernel with HIP events; zero_copy (default 1): kernels
+ * chunks); profiling = 1 brackets every stage with HIP events (sweep, traceback, D2H: three marker packets per run, ~10 us of a
+ * 0.17 ms step), 2 only the sweep (two packets; swmi_timing.traceback_ms stays 0), 0 (default) nothing; zero_copy (default 1): kernels
  * write results straight into pinned host memory instead of a D2H copy; device_strings (default 1): the traceback kernels
  * write both aligned strings of every alignment behind its packed ops (from the caller's bytes as uploaded), so the
  * alignment accessors hand out pointers; 0: records carry the 2-bit ops only and the host builds a string when it is asked

@@ -393,7 +393,8 @@ extern "C" int swmi_set_option(swmi_ctx *ctx, const char *name, int64_t value) {
     } else if (!strcmp(name, "zero_copy")) {
         ctx->zero_copy = value != 0;
     } else if (!strcmp(name, "profiling")) {
-        ctx->profiling = value != 0;
+        if (value < 0 || value > 2) return fail(SWMI_ERR_INVALID, "profiling must be 0, 1 (every stage) or 2 (the sweep only)");
+        ctx->profiling = (int)value;
     } else if (!strcmp(name, "arena_words_per_pair")) {
         if (value < 1) return fail(SWMI_ERR_INVALID, "arena_words_per_pair out of range");
         ctx->arena_words_per_pair = (uint64_t)value;
@@ -1132,7 +1133,7 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
         // dispatches instead of by events around them (the three events cost 3.5 us per run, tests/manual/prof_events_ab.py;
         // hipExtLaunchKernelGGL's start/stop events cost more: profiles/r02/ab_ext_events.txt)
         const bool split_now = rs.tb_split && !cells_exact && b->eff_mode == 1 && n_windows < 0xFFFFFFFFull;
-        const bool ext_timing = ctx->profiling && attempt == 0 && !whole_only && !n_res && !n_tf && !split_now && b->eff_mode == 1 &&
+        const bool ext_timing = ctx->profiling == 1 && attempt == 0 && !whole_only && !n_res && !n_tf && !split_now && b->eff_mode == 1 &&
                                 !fa.n_strip_items && !fa.n_col_items && ctx->ext_events;
         if (ctx->profiling && !ext_timing) HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
         if (attempt == 0 && !whole_only) {       // the workspace survives an arena-overflow retry
@@ -1160,7 +1161,9 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
         } else if (n_res + n_tf < np) {
             HIP_TRY(swmi_launch_traceback(&ta, ctx->stream, ext_timing ? ctx->ev[2] : nullptr, ext_timing ? ctx->ev[3] : nullptr));
         }
-        if (ctx->profiling && !ext_timing) HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
+        // (profiling = 2: only the sweep is bracketed -- two marker packets per run instead of three; each costs ~3.5 us of the step)
+        const bool time_all = ctx->profiling == 1;
+        if (time_all && !ext_timing) HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
 
         // without zero-copy: one D2H of header + pair outputs + as much of the arena as the previous run used
         // (plus slack); the rare remainder is fetched after the header has been read
@@ -1171,7 +1174,7 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
             if ((rc = b->h_result.reserve(a_off + arena_cap * 4))) return rc;
             HIP_TRY(hipMemcpyAsync(b->h_result.p, res, t_off + copy_recs * sizeof(AlnRec), hipMemcpyDeviceToHost, ctx->stream));
             HIP_TRY(hipMemcpyAsync((uint8_t *)b->h_result.p + a_off, res + a_off, copy_words * 4, hipMemcpyDeviceToHost, ctx->stream));
-            if (ctx->profiling) HIP_TRY(hipEventRecord(ctx->ev[4], ctx->stream));
+            if (time_all) HIP_TRY(hipEventRecord(ctx->ev[4], ctx->stream));
         }
         static const char *watchdog = getenv("SWMI_DEBUG_WATCHDOG");      // diagnostics: give up on a launch that does not end, show the kernel's marks
         if (watchdog) {
@@ -1218,8 +1221,8 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
         if (ctx->profiling) {
             float ms = 0;
             if (attempt == 0 || whole_only) { HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1])); rs.fill_ms += ms; }
-            HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[ext_timing ? 2 : 1], ctx->ev[3])); rs.tb_ms += ms;
-            if (!zc) { HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4])); rs.d2h_ms += ms; }
+            if (time_all) { HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[ext_timing ? 2 : 1], ctx->ev[3])); rs.tb_ms += ms; }
+            if (time_all && !zc) { HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4])); rs.d2h_ms += ms; }
         }
         if ((rc = dump_traceback_diagnostics(b, ta, np, n_tf))) return rc;
         if (attempt == 0 && (rc = dump_fill_diagnostics(b, fa, np))) return rc;
