@@ -62,22 +62,12 @@ class Batch:
     @classmethod
     def _view(cls, lib, handle, n_refs, n_reads, owner):
         """results-only batch owned by a Stream.  The view keeps the Stream alive (swmi_stream_close frees every result
-        batch), and Stream.close() invalidates it: a late call raises SwmiError instead of touching freed memory."""
+        batch), and Stream.close() sets its handle to None: the library answers a NULL batch with SWMI_ERR_INVALID, so a
+        late call raises SwmiError instead of touching freed memory."""
         b = cls.__new__(cls)
         b._ctx, b._lib, b._h, b.n_refs, b.n_reads, b._owned = None, lib, handle, n_refs, n_reads, False
         b._owner = owner
         return b
-
-    def __getattribute__(self, name):
-        # (a view whose Stream was closed has _h = None: every accessor passes it to the library, which must not see NULL
-        # silently turned into "batch is null" for some calls and a crash for others)
-        if name in Batch._NEEDS_HANDLE and object.__getattribute__(self, "_h") is None:
-            raise _capi.SwmiError(-1, "the batch is closed (freed, or the Stream that owned it was closed)")
-        return object.__getattribute__(self, name)
-
-    _NEEDS_HANDLE = frozenset(("run", "run_async", "wait", "timing", "pipeline_mode", "score", "n_alignments", "alignment",
-                               "alignments", "pair_results", "materialise_all", "ref_total", "ref_totals", "ref_match_sites",
-                               "ref_sites_packed"))
 
     def __init__(self, ctx, refs, reads):
         self._ctx = ctx

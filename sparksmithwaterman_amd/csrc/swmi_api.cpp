@@ -1050,6 +1050,11 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
         fa.col_items = n_col_items ? b->d_col_items.as<ColItem>() : nullptr;
         fa.n_col_items = (uint32_t)n_col_items;
         fa.strip_spins = ctx->dbg_strip_spins;
+        // split traceback: the walk-item queue; its counter is zeroed by the sweep kernel of the first attempt
+        const bool split_q = rs.tb_split && !cells_exact && b->eff_mode == 1 && n_windows < 0xFFFFFFFFull;
+        const uint64_t q_cap = std::min<uint64_t>(std::max<uint64_t>(cells_total, 1), 1ull << 24);
+        if (split_q && (rc = b->d_queue.reserve(256 + q_cap * sizeof(uint4)))) return rc;
+        fa.q_reset = split_q ? b->d_queue.as<uint32_t>() : nullptr;
 
         TraceArgs &ta = rs.ta;
         ta.seqw = fa.seqw; ta.refs = fa.refs; ta.reads = fa.reads; ta.pairs = fa.pairs;
@@ -1150,13 +1155,11 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
         // (the exact-size re-run of pairs whose lists overflowed takes one workgroup per pair: its lists have no per-window cap)
         const bool split = rs.tb_split && !cells_exact && b->eff_mode == 1 && n_windows < 0xFFFFFFFFull;
         if (split) {
-            const uint64_t q_cap = std::min<uint64_t>(std::max<uint64_t>(cells_total, 1), 1ull << 24);
-            if ((rc = b->d_queue.reserve(256 + q_cap * sizeof(uint4)))) return rc;
             ta.win_off = b->d_win_off.as<uint32_t>();
             ta.q_count = b->d_queue.as<uint32_t>();
             ta.q_items = (uint4 *)(b->d_queue.as<uint8_t>() + 256);
             ta.q_cap = (uint32_t)q_cap;
-            HIP_TRY(hipMemsetAsync(ta.q_count, 0, 4, ctx->stream));
+            if (attempt > 0 || whole_only) HIP_TRY(hipMemsetAsync(ta.q_count, 0, 4, ctx->stream));      // (no sweep kernel ran to zero it)
             HIP_TRY(swmi_launch_traceback_split(&ta, (uint32_t)n_windows, ctx->stream));
         } else if (n_res + n_tf < np) {
             HIP_TRY(swmi_launch_traceback(&ta, ctx->stream, ext_timing ? ctx->ev[2] : nullptr, ext_timing ? ctx->ev[3] : nullptr));

@@ -141,6 +141,7 @@ struct FillArgs {
     const ColItem  *col_items;   // mode 1: column chunks of single-strip pairs (few pairs, long references)
     uint32_t        n_col_items;
     uint32_t        strip_spins; // spin budget of the strip pipeline before it gives up (0: default)
+    uint32_t       *q_reset;     // split traceback: its walk-item counter, zeroed by the sweep kernel (a memset would be one more launch)
 };
 
 struct TraceArgs {

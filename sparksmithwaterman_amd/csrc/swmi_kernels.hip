@@ -793,6 +793,7 @@ __device__ __forceinline__ void fill_entry(const FillArgs &A) {
     if (pair >= A.n_pairs) return;
     const uint32_t lane = threadIdx.x & 63u;
     if (pair == 0 && lane == 0 && A.hdr) { A.hdr->reserved = 0; A.hdr->pad = 0; }   // arena reset for the traceback kernel that follows
+    if (pair == 0 && lane == 0 && A.q_reset) *A.q_reset = 0u;                        // ... and the split traceback's item counter
     const PairDesc pd = A.pairs[pair];
     if (MODE == SWMI_MODE_WINMAX && (pd.pad & SWMI_PAD_RESIDENT)) return;            // sw_resident_pairs_kernel does the whole pair
     const SeqDesc rd = A.refs[pd.ref_id];
