@@ -335,7 +335,8 @@ def main():
                 insts = (ipp["valu"] + ipp["salu"]) * len(refs) * len(reads)
                 nominal = 1024 * 2.4e9 / 2.0         # SIMDs x max clock / 2 cycles per wave64 VALU (the guide's nominal rate)
                 lone = 1024 * 2.4e9 / 4.0            # ... / 4 cycles: what ONE wave per SIMD can issue (guide, 'one wave alone: 4')
-                issue = {"insts_per_launch": insts, "achieved_ginst_s": round(insts / fill_avg_s / 1e9, 1),
+                issue = {"insts_per_launch": insts, "insts_source": ipp.get("source"),
+                         "achieved_ginst_s": round(insts / fill_avg_s / 1e9, 1),
                          "frac_of_nominal_2cyc": round(insts / fill_avg_s / nominal, 4),
                          "frac_of_one_wave_per_simd_4cyc": round(insts / fill_avg_s / lone, 4)}
         except Exception:

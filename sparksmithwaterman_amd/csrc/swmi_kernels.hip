@@ -1357,9 +1357,12 @@ __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDes
                     const bool valid = grp < 3u && rho_x >= 0 && j > dj + x && tx >= tmin;
                     // all three LDS reads are issued together (one latency): direction word, reference code, read code.
                     // Lanes without a cell read element 0 instead of branching around the loads.
-                    const uint32_t dw = tile_cur[valid ? (((uint32_t)tx >> 4) - wlo) * (R * WAVE) + kx * WAVE + lx : 0u];
-                    const uint32_t rc = ref_b[valid ? (jj - 1u) - 4u * cw0 : 0u];
-                    const uint32_t qc = read_b[valid ? i - 1u - di - x : 0u];
+                    uint32_t dw = tile_cur[valid ? (((uint32_t)tx >> 4) - wlo) * (R * WAVE) + kx * WAVE + lx : 0u];
+                    uint32_t rc = ref_b[valid ? (jj - 1u) - 4u * cw0 : 0u];
+                    uint32_t qc = read_b[valid ? i - 1u - di - x : 0u];
+                    // (all three in flight before anything waits: left alone, the compiler put the direction word's read
+                    //  behind the wait for the two codes -- a second LDS round trip in every iteration of the walk)
+                    asm volatile("" : "+v"(dw), "+v"(rc), "+v"(qc));
                     const uint32_t d = (dw >> (2u * (15u - ((uint32_t)tx & 15u)))) & 3u;
                     const bool mt = rc == qc;
                     const uint64_t vmask = BALLOT(valid);
