@@ -835,7 +835,8 @@ static int prepare_chunk(RunState &rs, const std::vector<Work> &work, size_t lo,
 }
 
 // SWMI_DEBUG_FILL=1: where the time of the traceback (per-pair ticks, walk / staging shares, the slowest pairs) and of the
-// sweep (ticks, wave placement by HW_ID) went.  Diagnostics only.
+// sweep (ticks, wave placement by HW_ID) went.  Diagnostics only.  (The traceback's per-pair counters are compiled into the
+// kernels only with `make KFLAGS=-DSWMI_TB_DIAG`: without it this prints zeros for them.)
 static int dump_traceback_diagnostics(swmi_batch *b, const TraceArgs &ta, size_t np, size_t n_tf) {
     if (!ta.dbg) return SWMI_OK;
     std::vector<unsigned long long> d(np * 4);

@@ -1098,6 +1098,14 @@ __device__ __forceinline__ uint32_t detect_cells(const TraceArgs &A, const PairD
 // there is no workgroup barrier after the cell list.
 // shared[]: [0] number of maximum cells, [4+4t ..] team t's request {strip, first block, windows, sequence number
 // (~0: the walker is done)}, [20+t] windows team t's helpers have delivered so far.
+// Per-pair diagnostics of the traceback (ticks of the walk and of the stagings, iterations, steps: SWMI_DEBUG_FILL=1) are compiled
+// in only with -DSWMI_TB_DIAG (make KFLAGS=-DSWMI_TB_DIAG): their counters lived in registers across the whole walk of a kernel
+// that sits at its 128-VGPR limit with spills.
+#ifdef SWMI_TB_DIAG
+#define TB_DBG (A.dbg != nullptr)
+#else
+#define TB_DBG false
+#endif
 template <int R, int TMODE, bool COOP, bool FULL = true>
 __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDesc pd, const PairOut po,
                                                const uint32_t lane, const uint32_t slot, const uint32_t nslots,
@@ -1154,7 +1162,7 @@ __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDes
         }
     };
 
-    const unsigned long long tk0 = A.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
+    const unsigned long long tk0 = TB_DBG ? __builtin_amdgcn_s_memtime() : 0ull;
     unsigned long long tk_walk = 0, tk_stage = 0, n_steps = 0, n_iters = 0;
     if (!read_staged)
         for (uint32_t w = lane; w < (m + 3u) / 4u; w += WAVE) lds_read[w] = readw[w];
@@ -1195,7 +1203,7 @@ __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDes
             uint32_t n_ops = 0;
             int begin = 0;
             while ((int)score > 0 && i != 0u && j != 0u) {     // (a positive score at row/column 0 cannot happen with consistent
-                const unsigned long long ts0 = A.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
+                const unsigned long long ts0 = TB_DBG ? __builtin_amdgcn_s_memtime() : 0ull;
                                                                //  data; the test keeps a corrupted workspace from walking off the matrix)
                 // ---- stage the window that holds the current cell's step ----
                 const uint32_t s = (i - 1u) / rps;
@@ -1228,9 +1236,9 @@ __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDes
                 const uint32_t cw1 = (16u * (wlo + nb) - 1u) >> 2;
                 WAVE_SYNC();
                 if (use_spec) {
-                    const unsigned long long tq0 = A.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
+                    const unsigned long long tq0 = TB_DBG ? __builtin_amdgcn_s_memtime() : 0ull;
                     team_wait();
-                    if (A.dbg) tk_walk += (__builtin_amdgcn_s_memtime() - tq0) << 32;
+                    if (TB_DBG) tk_walk += (__builtin_amdgcn_s_memtime() - tq0) << 32;
                     uint32_t *t = tile_cur; tile_cur = tile_alt; tile_alt = t;
                     lds_ref[lane] = spec_rv0;
                     if (lane + WAVE < SWMI_TB_REFWIN_WORDS) lds_ref[lane + WAVE] = spec_rv1;
@@ -1255,9 +1263,9 @@ __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDes
                     if (lane + WAVE < SWMI_TB_REFWIN_WORDS) lds_ref[lane + WAVE] = rv1;
                     if (COOP) {
                         // wait for the helpers' windows
-                        const unsigned long long tq0 = A.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
+                        const unsigned long long tq0 = TB_DBG ? __builtin_amdgcn_s_memtime() : 0ull;
                         team_wait();
-                        if (A.dbg) tk_walk += (__builtin_amdgcn_s_memtime() - tq0) << 32;     // (waiting counted in the upper half)
+                        if (TB_DBG) tk_walk += (__builtin_amdgcn_s_memtime() - tq0) << 32;     // (waiting counted in the upper half)
                     }
                     WAVE_SYNC();
                 }
@@ -1275,8 +1283,8 @@ __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDes
                     team_request((tile_alt == lds_tile ? 0u : 1u) | 2u, spec_wlo, nq, nq);
                 }
                 const int tmin = (int)(16u * wlo);
-                const unsigned long long tw0 = A.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
-                if (A.dbg) { tk_stage += tw0 - ts0; n_iters += 1ull << 32; }      // (stagings counted in the upper half)
+                const unsigned long long tw0 = TB_DBG ? __builtin_amdgcn_s_memtime() : 0ull;
+                if (TB_DBG) { tk_stage += tw0 - ts0; n_iters += 1ull << 32; }      // (stagings counted in the upper half)
 
 #ifdef SWMI_WALK_CHASE
                 // (Alternative walk, -DSWMI_WALK_CHASE: measured 0.084 ms against the 0.072 ms of the run-based walk below at the
@@ -1290,7 +1298,7 @@ __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDes
                 // scalar instructions per path step and no memory access, 7-15 steps per round trip whatever mix of gaps and
                 // alignment moves the path is made of.
                 for (;;) {
-                    ++n_iters;
+                    if (TB_DBG) ++n_iters;
                     const uint32_t na = lane >> 3, nb = lane & 7u;
                     const int rho_x = rho - (int)na;
                     const uint32_t rx = rho_x > 0 ? (uint32_t)rho_x : 0u;
@@ -1346,7 +1354,7 @@ __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDes
                 // One iteration then takes: [a gap move] + [the run of alignment moves that follows] + [the gap move
                 // that ends the run] -- about 4-5 path steps per LDS round trip on gappy paths, 21+ on clean ones.
                 for (;;) {
-                    ++n_iters;
+                    if (TB_DBG) ++n_iters;
                     const uint32_t grp = lane / 21u, x = lane - grp * 21u;        // lane 63: grp 3, idle
                     const uint32_t di = grp == 1u ? 1u : 0u, dj = grp == 2u ? 1u : 0u;
                     const int rho_x = rho - (int)di - (int)x;
@@ -1450,9 +1458,9 @@ __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDes
                     }
                 }
 #endif
-                if (A.dbg) tk_walk += __builtin_amdgcn_s_memtime() - tw0;
+                if (TB_DBG) tk_walk += __builtin_amdgcn_s_memtime() - tw0;
             }
-            n_steps += n_ops;
+            if (TB_DBG) n_steps += n_ops;
             WAVE_SYNC();
 
             // ---- the record: a table entry + the payload (ops packed 2 bits each, 16 per dword [+ the two aligned strings]) ----
@@ -1501,7 +1509,7 @@ __device__ __forceinline__ void traceback_pair(const TraceArgs &A, const PairDes
     }
     if (COOP && lane == 0)                                                         // releases this team's helpers
         __hip_atomic_store(const_cast<uint32_t *>(&shared[7u + 4u * slot]), 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    if (A.dbg && lane == 0 && slot == 0) {
+    if (TB_DBG && lane == 0 && slot == 0) {
         A.dbg[4 * pd.out_id] = __builtin_amdgcn_s_memtime() - tk0;
         A.dbg[4 * pd.out_id + 1] = tk_walk;
         A.dbg[4 * pd.out_id + 2] = n_steps | (tk_stage << 16);       // (steps < 65536 in the diagnostics runs)
