@@ -108,6 +108,10 @@ void        swmi_default_params(swmi_params *p);
  *                of at most 2560 -- is swept in the TRANSPOSED layout (reference columns on the lanes, the read streaming
  *                through) and traced back in the same launch (sw_tfused_kernel: block tasks and walk items shared by the
  *                wavefronts of a workgroup); 0 or -1 (default): never -- measured slower than the two-kernel pipeline.
+ * scores_only (default 0): 1 = the sweep only: every pair's score and MapRef's totals (swmi_pair_score, swmi_ref_total(s),
+ *                swmi_stream_totals, swmi_batch_pair_results with n_alignments = NULL); the tied-maximum lists and the alignments
+ *                are not computed and their accessors fail.  For a driver that reduces to the winning references first and aligns
+ *                only those in full (the reference's driver discards every other reference's alignments, Distribution.java:341-353).
  * stream_keep_records (default 1): 0 = a stream drops every chunk's alignment records once its scores, counts and totals are
  *                taken -- for a driver that reduces to the winning references and aligns those again (Distribution.java:341-353
  *                discards every other reference's alignments too); the alignment accessors of such chunks fail.

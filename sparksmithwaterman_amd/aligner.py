@@ -140,6 +140,14 @@ class Batch:
                                                 na.ctypes.data_as(C.POINTER(C.c_uint64)), n))
         return sc, na
 
+    def scores(self):
+        """every pair's score as a numpy int32 array (also after a scores_only run, which has no alignment counts)"""
+        import numpy as np
+        n = self.n_refs * self.n_reads
+        sc = np.empty(n, dtype=np.int32)
+        check(self._lib.swmi_batch_pair_results(self._h, sc.ctypes.data_as(C.POINTER(C.c_int32)), None, n))
+        return sc
+
     def materialise_all(self):
         """Index the records and build every alignment string natively; returns (n_alignments, n_chars)."""
         na, nc = C.c_uint64(), C.c_uint64()

@@ -142,6 +142,7 @@ struct swmi_ctx {
                                             // durations, as rocprofv3 shows them) -- measured 8-12 us per run DEARER than three hipEventRecord, so off
     int tfused = -1;                        // transposed sweep + traceback by one wavefront per pair (swmi_tfused.hip): -1 automatic, 0 never, 1 whenever a pair qualifies
     int resident = -1;                      // small pairs handled by one wavefront with the direction field in LDS: -1 automatic, 0 never, 1 whenever it fits
+    int scores_only = 0;                    // 1: the sweep only -- every pair's score (and MapRef's totals), no tied-maximum lists, no alignments
     int stream_keep_records = 1;            // streams: 0 = a chunk's alignment records are dropped once its scores and counts are taken (a driver
                                             // that only needs totals and re-aligns its few winners, Distribution.java:341-353)
     int device_strings = 1;                 // the traceback kernels write both aligned strings behind every record (swmi_emit.h); 0: 2-bit ops only, strings built by the host
@@ -236,7 +237,7 @@ struct swmi_batch {
         int tfused_opt = -1;
         size_t n_tf = 0;
         uint32_t tf_max_m = 0, tf_max_n = 0, tf_max_path = 0;
-        bool exact = false;
+        bool exact = false, scores_only = false;
         uint32_t col_chunks_opt = 0;
         bool reverse_strips = false;
     } prep;
@@ -254,6 +255,7 @@ struct swmi_batch {
     std::vector<RawChunk> raw_chunks;
     bool indexed = false;
     bool rec_strings = false;               // the records of the last run carry both aligned strings (option device_strings)
+    bool scores_only = false;               // the last run computed scores only (option scores_only): no counts, no alignments
     bool records_dropped = false;           // a streamed chunk whose records were not kept (option stream_keep_records = 0)
     std::vector<HostAln> alns;              // grouped by pair, ordered as OptAlignments returns them
     std::vector<char> str_buf;              // every alignment's two NUL-terminated strings, at fixed offsets (str_at)
@@ -380,6 +382,8 @@ extern "C" int swmi_set_option(swmi_ctx *ctx, const char *name, int64_t value) {
     } else if (!strcmp(name, "resident")) {
         if (value < -1 || value > 1) return fail(SWMI_ERR_INVALID, "resident must be -1 (automatic), 0 or 1");
         ctx->resident = (int)value;
+    } else if (!strcmp(name, "scores_only")) {
+        ctx->scores_only = value != 0;
     } else if (!strcmp(name, "stream_keep_records")) {
         ctx->stream_keep_records = value != 0;
     } else if (!strcmp(name, "device_strings")) {
@@ -630,7 +634,7 @@ static int prepare_chunk(RunState &rs, const std::vector<Work> &work, size_t lo,
                           memcmp(&pr.params, &b->params, sizeof(swmi_params)) == 0 && b->pairs_dev_ptr == b->d_pairs.p &&
                           b->pairs_on_device.size() == np * sizeof(PairDesc) && pr.col_chunks_opt == ctx->col_chunks &&
                           pr.reverse_strips == (ctx->dbg_reverse_strips != 0) && pr.resident_opt == ctx->resident &&
-                          pr.tfused_opt == ctx->tfused && pr.exact == (cells_exact != nullptr);
+                          pr.tfused_opt == ctx->tfused && pr.exact == (cells_exact != nullptr) && pr.scores_only == (ctx->scores_only != 0);
     if (prepared) {
         dir_words = pr.dir_words; seam_words = pr.seam_words; max_path = pr.max_path; max_read = pr.max_read;
         n_strip_items = pr.n_strip_items; n_col_items = pr.n_col_items; n_windows = pr.n_windows;
@@ -650,7 +654,7 @@ static int prepare_chunk(RunState &rs, const std::vector<Work> &work, size_t lo,
     // lane.  (The exact-size re-run of pairs with more tied maxima than an LDS list holds takes the ordinary path.)
     // (measured, profiles/r02/sweeps_*.md: below ~300 pairs the launch is latency-bound and the split traceback, which
     // spreads a pair's windows and alignments over many wavefronts, is faster)
-    const bool res_possible = b->eff_mode == 1 && !cells_exact && ctx->resident != 0 && (ctx->resident == 1 || np >= 256) &&
+    const bool res_possible = b->eff_mode == 1 && !cells_exact && !ctx->scores_only && ctx->resident != 0 && (ctx->resident == 1 || np >= 256) &&
                               P.match <= 7 && P.match >= -8 && P.mismatch >= -8 && P.mismatch <= 0 && P.gap <= 0;
     auto res_need_words = [&](uint32_t m_, uint32_t n_, uint32_t &opw) -> uint64_t {
         const uint32_t R_ = swmi_rows_per_lane(m_), lact = (m_ + R_ - 1) / R_;
@@ -672,7 +676,7 @@ static int prepare_chunk(RunState &rs, const std::vector<Work> &work, size_t lo,
     // Its sweep needs 20 % fewer instructions, but its traceback (one wavefront per block of a pair) does not beat the
     // workgroup-per-pair kernel: measured 0.170 ms against 0.088 + 0.071 at the headline, and slower for big batches (LDS and
     // registers hold it to one or two wavefronts per SIMD).  Kept as an option, tested in every GPU parity test; not chosen.
-    const bool tf_possible = b->eff_mode == 1 && !cells_exact && ctx->tfused == 1 &&      // (-1, automatic: not chosen -- DESIGN.md 4.4)
+    const bool tf_possible = b->eff_mode == 1 && !cells_exact && !ctx->scores_only && ctx->tfused == 1 &&      // (-1, automatic: not chosen -- DESIGN.md 4.4)
                              P.match > 0 && P.match <= 7 && P.mismatch >= -8 && P.mismatch <= P.match && P.gap < 0 && P.gap >= -64;
     if ((cols_possible || res_maybe || tf_possible) && !b->acgt_known) {
         // the fast-symbol flags are derived on the device by the encode kernel
@@ -828,6 +832,7 @@ static int prepare_chunk(RunState &rs, const std::vector<Work> &work, size_t lo,
         pr.resident_opt = ctx->resident; pr.exact = cells_exact != nullptr;
         pr.tfused_opt = ctx->tfused; pr.n_tf = n_tf; pr.tf_max_m = tf_max_m; pr.tf_max_n = tf_max_n; pr.tf_max_path = tf_max_path;
         pr.col_chunks_opt = ctx->col_chunks; pr.reverse_strips = ctx->dbg_reverse_strips != 0;
+        pr.scores_only = ctx->scores_only != 0;
     }
     rs.prep_us += std::chrono::duration<double, std::micro>(p1 - p0).count();
     rs.prep_upload_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - p1).count();
@@ -1155,7 +1160,14 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
         if (attempt == 0) b->timing.tfused_pairs += (uint32_t)n_tf;
         // (the exact-size re-run of pairs whose lists overflowed takes one workgroup per pair: its lists have no per-window cap)
         const bool split = rs.tb_split && !cells_exact && b->eff_mode == 1 && n_windows < 0xFFFFFFFFull;
-        if (split) {
+        const bool sweep_only = ctx->scores_only != 0 && !cells_exact;
+        if (sweep_only) {
+            // option scores_only: the pair outputs as the sweep kernels left them (the traceback kernels, which otherwise mirror
+            // them into the host block, do not run)
+            if ((rc = b->h_result.reserve(a_off + arena_cap * 4))) return rc;
+            HIP_TRY(hipMemcpyAsync((uint8_t *)b->h_result.p + result_out_off(), res + result_out_off(), np * sizeof(PairOut),
+                                   hipMemcpyDeviceToHost, ctx->stream));
+        } else if (split) {
             ta.win_off = b->d_win_off.as<uint32_t>();
             ta.q_count = b->d_queue.as<uint32_t>();
             ta.q_items = (uint4 *)(b->d_queue.as<uint8_t>() + 256);
@@ -1174,7 +1186,7 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
         // (header, pair outputs and as many table entries and arena words as the previous run used, plus slack)
         const uint64_t copy_words = std::min<uint64_t>(arena_cap, std::max<uint64_t>(256, np * ctx->arena_copy_wpp));
         const uint64_t copy_recs = std::min<uint64_t>(tab_cap, np * ctx->recs_per_pair_x16 / 16 + 64);
-        if (!zc) {
+        if (!zc && !sweep_only) {
             if ((rc = b->h_result.reserve(a_off + arena_cap * 4))) return rc;
             HIP_TRY(hipMemcpyAsync(b->h_result.p, res, t_off + copy_recs * sizeof(AlnRec), hipMemcpyDeviceToHost, ctx->stream));
             HIP_TRY(hipMemcpyAsync((uint8_t *)b->h_result.p + a_off, res + a_off, copy_words * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -1231,6 +1243,21 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
         if ((rc = dump_traceback_diagnostics(b, ta, np, n_tf))) return rc;
         if (attempt == 0 && (rc = dump_fill_diagnostics(b, fa, np))) return rc;
         const uint8_t *h = (const uint8_t *)b->h_result.p;
+        if (sweep_only) {
+            // scores only: a pair swept by several wavefronts (column chunks, strips) has only its maximum combined, and a
+            // maximum of 0 is the degenerate case (what finish_pair does in the traceback kernels)
+            outs.assign((const PairOut *)(h + result_out_off()), (const PairOut *)(h + result_out_off()) + np);
+            for (size_t k = 0; k < np; k++) {
+                PairOut &o = outs[k];
+                if (o.score <= 0 && !(o.flags & SWMI_F_DEGENERATE)) {
+                    const uint32_t pair = work[lo + k].pair;
+                    o.score = 0; o.flags = SWMI_F_DEGENERATE;
+                    o.n_cells = (uint64_t)b->read_desc[pair % b->n_reads].len * b->ref_desc[pair / b->n_reads].len;
+                }
+                o.flags &= SWMI_F_DEGENERATE;
+            }
+            return SWMI_OK;
+        }
         ArenaHdr hdr_copy{};
         const ArenaHdr *hdr = (const ArenaHdr *)h;
         bool overflow;
@@ -1317,6 +1344,8 @@ static int settle_raw(swmi_batch *b) {
 // Turns the record tables of the last run into per-pair alignment lists (first use of an alignment accessor).
 static int ensure_indexed(swmi_batch *b) {
     if (b->indexed) return SWMI_OK;
+    if (b->scores_only)
+        return fail(SWMI_ERR_INVALID, "the batch was run with scores_only = 1: scores and totals only, no alignments");
     if (b->records_dropped)
         return fail(SWMI_ERR_INVALID, "this chunk's alignment records were not kept (option stream_keep_records = 0): scores, counts and totals only");
     const std::vector<Work> &work = b->work;
@@ -1425,6 +1454,7 @@ extern "C" int swmi_batch_run(swmi_ctx *ctx, swmi_batch *b, const swmi_params *p
     }
     b->params = *p;
     b->has_run = false;
+    b->scores_only = ctx->scores_only != 0;
 
     const uint32_t n_refs = b->n_refs, n_reads = b->n_reads;
     const uint64_t n_pairs = (uint64_t)n_refs * n_reads;
@@ -1721,6 +1751,8 @@ extern "C" int swmi_pair_score(const swmi_batch *b, uint64_t pair, int32_t *scor
 extern "C" int swmi_pair_n_alignments(const swmi_batch *b, uint64_t pair, uint64_t *n, uint32_t *flags) {
     int rc = check_pair(b, pair);
     if (rc) return rc;
+    if (b->scores_only && !(b->pairs[pair].flags & SWMI_PAIR_DEGENERATE))
+        return fail(SWMI_ERR_INVALID, "the batch was run with scores_only = 1: the number of alignments was not computed");
     if (n) *n = b->pairs[pair].n_cells;
     if (flags) *flags = b->pairs[pair].flags;
     return SWMI_OK;
@@ -1732,6 +1764,8 @@ extern "C" int swmi_batch_pair_results(const swmi_batch *b, int32_t *scores, uin
     if (!b->has_run) return fail(SWMI_ERR_INVALID, "batch has no results (run it first)");
     if (n != (uint64_t)b->n_refs * b->n_reads) return fail(SWMI_ERR_RANGE, "the batch has %llu pairs, not %llu",
                                                            (unsigned long long)b->n_refs * b->n_reads, (unsigned long long)n);
+    if (b->scores_only && n_alignments)
+        return fail(SWMI_ERR_INVALID, "the batch was run with scores_only = 1: pass n_alignments = NULL");
     for (uint64_t k = 0; k < n; k++) {
         if (scores) scores[k] = b->pairs[k].score;
         if (n_alignments) n_alignments[k] = b->pairs[k].n_cells;
@@ -2114,6 +2148,7 @@ static int stream_process(swmi_stream *s, swmi_stream::Slot &sl, StreamChunk *c)
         b->raw_ext = nullptr; b->rtab_ext = nullptr;
     }
     r->rec_strings = b->rec_strings;
+    r->scores_only = b->scores_only;
     r->indexed = false;
     r->ref_view_ready.assign(n_refs, 0);
     r->ref_sites.assign(n_refs, {});
@@ -2186,7 +2221,7 @@ extern "C" int swmi_stream_open(swmi_ctx *ctx, const swmi_params *p, const uint8
         sl.ctx->profiling = ctx->profiling; sl.ctx->mode = ctx->mode; sl.ctx->zero_copy = ctx->zero_copy;
         sl.ctx->tb_split = ctx->tb_split; sl.ctx->col_chunks = ctx->col_chunks; sl.ctx->resident = ctx->resident; sl.ctx->tfused = ctx->tfused;
         sl.ctx->auto_ties_x100 = ctx->auto_ties_x100; sl.ctx->arena_words_per_pair = ctx->arena_words_per_pair;
-        sl.ctx->device_strings = ctx->device_strings;
+        sl.ctx->device_strings = ctx->device_strings; sl.ctx->scores_only = ctx->scores_only;
         sl.ctx->spin_us = 50;                    // (a chunk takes milliseconds: the slot threads mostly block)
         sl.shell = new swmi_batch;
     }

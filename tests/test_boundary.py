@@ -183,3 +183,39 @@ def test_strip_pipeline_give_up_falls_back_to_one_wave_sweep():
     assert b.score(0) == orc.opt_alignments((refs[0], reads[0]))[0]
     b.free()
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_scores_only_is_the_sweep_alone():
+    """option scores_only: every pair's score and MapRef's totals from the sweep kernels alone -- equal to the full path's, for
+    every sweep shape (one wavefront, column chunks, strips of a long read, a byte alphabet, degenerate pairs) -- and the accessors
+    of what was not computed fail instead of inventing it.  Streams carry the option to their chunks."""
+    import numpy as np
+    import random
+    rng = random.Random(17)
+    refs = ["".join(rng.choice("ACGT") for _ in range(n)) for n in (30, 400, 2100, 5000)] + ["GGGG", "acgtnACGTNxx" * 20]
+    reads = ["".join(rng.choice("ACGT") for _ in range(m)) for m in (20, 150, 300)] + ["TTTT", refs[2][100:240].lower()]
+    ctx = sw.Context(0)
+    full = ctx.upload(refs, reads).run()
+    want_scores, _ = full.pair_results()
+    want_totals = full.ref_totals()
+    ctx.set_option("scores_only", 1)
+    b = ctx.upload(refs, reads).run()
+    assert list(b.scores()) == list(want_scores) and list(b.ref_totals()) == list(want_totals)
+    assert b.score(7) == int(want_scores[7])
+    deg = [p for p in range(len(refs) * len(reads)) if want_scores[p] == 0]
+    assert deg and b.n_alignments(deg[0]) == full.n_alignments(deg[0])           # (a maximum of 0: m * n, known without a traceback)
+    live = int(np.argmax(want_scores))
+    for call in (lambda: b.n_alignments(live), lambda: b.alignments(live), lambda: b.pair_results(), lambda: b.ref_match_sites(0),
+                 lambda: b.ref_sites_packed()):
+        with pytest.raises(sw.SwmiError):
+            call()
+    st = ctx.stream(reads, slots=2, chunk_bytes=64 << 10).push(refs).finish()
+    assert list(st.totals()) == list(want_totals)
+    st.close()
+    ctx.set_option("scores_only", 0)
+    again = ctx.upload(refs, reads).run()
+    assert again.alignments(live) == full.alignments(live)
+    for x in (full, b, again):
+        x.free()
+    ctx.close()
