@@ -1476,7 +1476,7 @@ extern "C" int swmi_batch_run(swmi_ctx *ctx, swmi_batch *b, const swmi_params *p
     b->eff_mode = (ctx->mode == 1 && (p->mismatch > 0 || p->gap > 0)) ? 2u : ctx->mode;
     // (measured, profiles/r02/sweeps_*.md: with ~5 alignments per pair the split traceback wins up to ~200 pairs; from a
     // few hundred pairs on one workgroup per pair keeps every SIMD busy anyway and its teams share the window re-sweeps)
-    if (ctx->tb_split < 0 && b->eff_mode == 1 && n_pairs >= 64 && n_pairs <= 256 &&
+    if (ctx->tb_split < 0 && !ctx->scores_only && b->eff_mode == 1 && n_pairs >= 64 && n_pairs <= 256 &&
         (b->auto_choice < 0 || memcmp(&b->auto_params, p, sizeof(swmi_params)) != 0)) {
         // Grain of the mode-1 traceback, chosen once per batch and parameter set: a sample of the pairs is aligned and the
         // tied maxima per pair are counted.  Periodic references (the reference's own EngineerData sets: every period ends
