@@ -901,6 +901,13 @@ static int dump_fill_diagnostics(swmi_batch *b, const FillArgs &fa, size_t np) {
     if (!fa.dbg) return SWMI_OK;
     std::vector<unsigned long long> d(np * 2);
     HIP_TRY(hipMemcpy(d.data(), fa.dbg, np * 16, hipMemcpyDeviceToHost));
+#ifdef SWMI_STRIP_DIAG
+    // strip pipeline (reads of two strips or more): see fill_pair
+    for (size_t k = 0; k < np && k < 8; k++)
+        fprintf(stderr, "[swmi strip dbg] pair %zu: strip 0 lifetime %llu ticks, %llu waiting before publications; strip 1 lifetime %llu, "
+                "%llu polls, %llu ticks in polls, %llu waiting for seam groups\n", k, d[2 * k] >> 32, d[2 * k] & 0xFFFFFFFFull,
+                d[2 * k + 1] >> 40, (d[2 * k + 1] >> 32) & 0xFF, (d[2 * k + 1] >> 16) & 0xFFFF, d[2 * k + 1] & 0xFFFF);
+#endif
     unsigned long long ev = 0, cyc = 0, evmax = 0, cmax = 0, cmin = ~0ull;
     for (size_t k = 0; k < np; k++) {
         ev += d[2 * k]; cyc += d[2 * k + 1];

@@ -214,6 +214,11 @@ record_max_cells(int h0, int h1, int h2, int h3, uint32_t t, uint32_t lane_eff, 
 // ------------------------------------------------------------------------------------------------
 // sweep state of one wavefront
 // ------------------------------------------------------------------------------------------------
+#ifdef SWMI_STRIP_DIAG
+#define SWMI_SD(...) __VA_ARGS__
+#else
+#define SWMI_SD(...)
+#endif
 template <int R>
 struct FillState {
     int h[R];            // H of the lane's rows: read by even steps of a block, written by odd ones
@@ -227,6 +232,9 @@ struct FillState {
     int lmax;            // WINMAX: this lane's maximum H since the last checkpoint
     uint32_t events;     // slow-path entries (diagnostics only)
     bool dbg_skip;       // diagnostics only
+#ifdef SWMI_STRIP_DIAG
+    unsigned long long dg_pub;    // ticks spent waiting before progress publications
+#endif
 };
 
 // read-side operands of this lane's rows, and a zero H column
@@ -268,6 +276,20 @@ __device__ __forceinline__ void handle_pending(FillState<R> &S, const int (&hv)[
     S.cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)tc);
 }
 
+typedef uint32_t Words4 __attribute__((ext_vector_type(4)));
+typedef const Words4 __attribute__((address_space(4))) *ConstWords4;     // constant address space: uniform loads become s_load
+
+// acc with lane `l` (0..15, a constant after unrolling) replaced by the scalar v
+__device__ __forceinline__ int writelane_const(int acc, const int v, const uint32_t l) {
+#define SWMI_WL(L) case L: asm("v_writelane_b32 %0, %1, " #L : "+v"(acc) : "s"(v)); break;
+    switch (l) {
+    SWMI_WL(0) SWMI_WL(1) SWMI_WL(2) SWMI_WL(3) SWMI_WL(4) SWMI_WL(5) SWMI_WL(6) SWMI_WL(7)
+    SWMI_WL(8) SWMI_WL(9) SWMI_WL(10) SWMI_WL(11) SWMI_WL(12) SWMI_WL(13) SWMI_WL(14) SWMI_WL(15)
+    }
+#undef SWMI_WL
+    return acc;
+}
+
 // 16 anti-diagonal steps t = t0 .. t0+15.  PRED: lanes may be outside their column range (ramp-up /
 // ramp-down blocks); otherwise every lane below `lact` is inside it for all 16 steps.
 //
@@ -282,13 +304,26 @@ __device__ __forceinline__ void fill_block16(FillState<R> &S, const uint4 w, con
                                              const int gap, const int vmat, const int vmis,
                                              const int seamv, const bool reads_seam, const bool feeds_seam,
                                              int32_t *__restrict__ seam_out,
-                                             uint2 *__restrict__ cells, const uint32_t ccap) {
+                                             uint2 *__restrict__ cells, const uint32_t ccap,
+                                             uint32_t *pub_slot = nullptr, const uint32_t pub_val = 0u) {
     constexpr bool DIRS = MODE == SWMI_MODE_FIELD || MODE == SWMI_MODE_REPLAY || MODE == SWMI_MODE_DETECT;
     constexpr bool TRACK = MODE == SWMI_MODE_FIELD || MODE == SWMI_MODE_SCORE;     // deferred tied-maximum events
     constexpr bool LMAX = MODE == SWMI_MODE_WINMAX;                                  // per-lane running maximum only
     constexpr bool DETECT = MODE == SWMI_MODE_DETECT;                                // list the cells equal to S.thr
     constexpr bool FEEDS = MODE == SWMI_MODE_FIELD || MODE == SWMI_MODE_SCORE || MODE == SWMI_MODE_WINMAX;   // sweep (writes seam rows)
     using C = Cells<R, ACGT, DIRS ? STRICT : false, DIRS>;
+    int seam_acc = 0;
+    // PIPE: "the blocks before this one are complete" (pub_val) is published as late as possible before this block's own
+    // seam stores: the wait then covers stores that were issued a block ago, not a moment ago
+    auto publish = [&]() {
+        if (PIPE && pub_val) {
+            SWMI_SD(const unsigned long long dg2 = __builtin_amdgcn_s_memtime();)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            SWMI_SD(S.dg_pub += __builtin_amdgcn_s_memtime() - dg2;)
+            if (lane == 0) __hip_atomic_store(pub_slot, pub_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    if (PRED) publish();
 #pragma unroll
     for (uint32_t s = 0; s < 16; ++s) {
         const int (&hin)[R] = (s & 1u) ? S.g : S.h;
@@ -311,9 +346,9 @@ __device__ __forceinline__ void fill_block16(FillState<R> &S, const uint4 w, con
         S.rb = wave_shr1(feed, S.rb);
         int nin;
         if (MULTI) {
-            int topn = 0;
-            if (reads_seam) topn = __builtin_amdgcn_readlane(seamv, s);
-            nin = wave_shr1(topn, hin[R - 1]);
+            // seamv is 0 in every lane of a strip with no seam above it: no branch on reads_seam (it cost an exec-masked
+            // branch per step, 9 instructions where 3 do)
+            nin = wave_shr1(__builtin_amdgcn_readlane(seamv, s), hin[R - 1]);
         } else {
             nin = wave_shr1_zero(hin[R - 1]);
         }
@@ -362,11 +397,9 @@ __device__ __forceinline__ void fill_block16(FillState<R> &S, const uint4 w, con
                     for (int k = 0; k < R; ++k) S.lmax = S.lmax > hout[k] ? S.lmax : hout[k];
                 }
             }
-            if (MULTI && FEEDS && feeds_seam && lane == WAVE - 1) {
-                // PIPE: another wavefront (possibly on another XCD) is already reading this row: device-coherent store
-                if (PIPE) __hip_atomic_store(seam_out + (t0 + s - lane + 1), hout[R - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                else      seam_out[t0 + s - lane + 1] = hout[R - 1];
-            }
+            // seam row: lane 63's last row of this step goes to lane s of seam_acc (v_readlane + v_writelane); one 64-byte
+            // store per block below instead of an exec-masked branch, a 64-bit address and a one-lane store per step
+            if (MULTI && FEEDS) seam_acc = writelane_const(seam_acc, __builtin_amdgcn_readlane(hout[R - 1], WAVE - 1), s);
         }
         S.nprev = nin;
         if (DETECT) {
@@ -392,6 +425,14 @@ __device__ __forceinline__ void fill_block16(FillState<R> &S, const uint4 w, con
                 handle_pending<R>(S, hin, t0 + s - 1u, lane_eff, n, row0, m, cells, ccap);
             S.ev_prev = ev;
         }
+    }
+    if (!PRED) publish();
+    if (MULTI && FEEDS && !PRED && feeds_seam && lane < 16u) {
+        // a steady block of a strip that feeds a seam has all 64 lanes on rows: lane 63 was on column t0 + s - 62 (1-based)
+        // at step s.  PIPE: another wavefront (possibly on another XCD) is already reading this row: device-coherent store
+        int32_t *dst = seam_out + (t0 - (WAVE - 2u)) + lane;
+        if (PIPE) __hip_atomic_store(dst, seam_acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else      *dst = seam_acc;
     }
 }
 
@@ -424,12 +465,16 @@ __device__ __forceinline__ StripGeom strip_geom(uint32_t m, uint32_t n, uint32_t
 // PIPE (mode 1, MULTI): this wavefront sweeps only strip `my_strip`; the wavefront of strip s-1 runs a few blocks ahead
 // and publishes its progress, the one of strip s+1 follows -- a systolic pipeline of strips over wavefronts, so a
 // 10 kbp read is swept in about the time of ONE strip instead of 40.
+#define SWMI_PIPE_PUBLISH 4u      // blocks between two publications of a strip's progress
 template <int R, bool ACGT, bool STRICT, bool MULTI, int MODE, bool PIPE = false>
 __device__ __forceinline__ void fill_pair(const FillArgs &A, const PairDesc pd, const uint32_t lane, const uint32_t my_strip = 0u) {
     const SeqDesc rd = A.refs[pd.ref_id];
     const SeqDesc qd = A.reads[pd.read_id];
-    const uint32_t n = rd.len, m = qd.len;
-    const uint32_t *__restrict__ refw = A.seqw + rd.boff;
+    // PIPE: the geometry in scalar registers, so that the block counter is one and the reference words can come through
+    // the scalar cache: a vector load's s_waitcnt vmcnt also waits for every store issued before it, the device-scope seam
+    // stores among them
+    const uint32_t n = PIPE ? uni(rd.len) : rd.len, m = PIPE ? uni(qd.len) : qd.len;
+    const uint32_t *__restrict__ refw = A.seqw + (PIPE ? uni(rd.boff) : rd.boff);
     const uint32_t *__restrict__ readw = A.seqw + qd.boff;
     const int match = A.match, mismatch = A.mismatch, gap = A.gap;
     constexpr uint32_t HMODE = MODE == SWMI_MODE_FIELD ? 0u : (MODE == SWMI_MODE_WINMAX ? 1u : 2u);
@@ -446,6 +491,9 @@ __device__ __forceinline__ void fill_pair(const FillArgs &A, const PairDesc pd, 
     S.ev_prev = 0;
     S.events = 0;
     S.dbg_skip = A.dbg && (A.dbg_pad != 0);
+#ifdef SWMI_STRIP_DIAG
+    S.dg_pub = 0;
+#endif
     const unsigned long long t_start = A.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
 
     const uint32_t s_begin = PIPE ? my_strip : 0u, s_end = PIPE ? my_strip + 1u : G.n_strips;
@@ -481,39 +529,56 @@ __device__ __forceinline__ void fill_pair(const FillArgs &A, const PairDesc pd, 
 
         const uint32_t nblk = (T + 15u) / 16u;
         const uint4 *__restrict__ refq = reinterpret_cast<const uint4 *>(refw);   // images are 16-byte aligned
-        uint4 wnext = refq[0];
-        // seam_in[16tb + 1 + lane] for lanes 0..15: N of lane 0 for the 16 steps of block tb -- loaded one block ahead,
-        // like the base codes, so that the sweep never waits for it
-        // PIPE: column c of the seam row is stored by the producer's lane 63 at step c + 62; the columns of block x are
-        // complete when the producer has finished block x + 4
+        const ConstWords4 refq_s = (ConstWords4)(uintptr_t)refw;                  // the same through the scalar cache (read-only data)
+        auto ref_words = [&](uint32_t i) -> uint4 {
+            if (PIPE) { const Words4 v = refq_s[i]; return make_uint4(v.x, v.y, v.z, v.w); }
+            return refq[i];
+        };
+        uint4 wnext = ref_words(0u);
+        // The seam row above this strip is read in GROUPS of 64 columns (4 blocks): seam_in[64g + 1 + lane], one coalesced
+        // load per group, issued one group ahead; a block takes its 16 values (N of lane 0 for its 16 steps) from the
+        // group register with one ds_bpermute.
+        // PIPE: column c of the seam row is stored by the producer's lane 63 at step c + 62, so the columns of block x are
+        // complete when the producer has finished block x + 4; the producer publishes its progress every SWMI_PIPE_PUBLISH
+        // blocks and the polled value is kept, so a consumer that is behind does not poll at all: ~24 polls per 254 blocks
+        // (a poll and a wait for the stores' acknowledgements per block: 0.415 ms at 257 x 4000, this way 0.357;
+        // profiles/r03/strip_pipeline.md).
         const uint32_t nblk_prod = (n + WAVE - 1u + 15u) / 16u;
         bool gave_up = false;
-        auto load_seam = [&](uint32_t tb) -> int {
+        uint32_t prod_seen = 0u;
+#ifdef SWMI_STRIP_DIAG
+        // -DSWMI_STRIP_DIAG + SWMI_DEBUG_FILL=1: where a strip's wavefront waits (s_memtime ticks, 10 ns)
+        unsigned long long dg_poll = 0, dg_grp = 0, dg_polls = 0;
+#endif
+        auto load_group = [&](uint32_t g) -> int {
+            const uint32_t col = 64u * g + 1u + lane;
+            if (64u * g >= n) return 0;
             if (PIPE) {
-                const uint32_t need = tb + 5u < nblk_prod ? tb + 5u : nblk_prod;
+                const uint32_t need = 4u * g + 8u < nblk_prod ? 4u * g + 8u : nblk_prod;
                 // the give-up is progress-based: the budget (~60 ms of s_sleep by default) restarts whenever the producer
                 // advances, so a slow producer is waited for and only one that does not move at all is abandoned -- the host
                 // then re-runs the chunk with the one-wavefront sweep, which needs no other workgroup (swmi_api.cpp)
                 const uint32_t budget = A.strip_spins ? A.strip_spins : (1u << 18);
-                uint32_t spins = 0, seen = 0xFFFFFFFFu;
-                while (!gave_up) {
-                    const uint32_t p = __hip_atomic_load(progress + (s - 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (p >= need) break;
-                    if (p != seen) { seen = p; spins = 0; }
+                uint32_t spins = 0;
+                SWMI_SD(const unsigned long long dg0 = __builtin_amdgcn_s_memtime(); if (prod_seen < need) dg_polls++;)
+                while (prod_seen < need && !gave_up) {
+                    const uint32_t p = __builtin_amdgcn_readfirstlane(
+                        __hip_atomic_load(progress + (s - 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    if (p != prod_seen) { prod_seen = p; spins = 0; continue; }
                     __builtin_amdgcn_s_sleep(8);
                     if (++spins > budget) {
                         gave_up = true;
                         if (lane == 0 && A.err_host) *A.err_host = 1u;
                     }
                 }
+                SWMI_SD(dg_poll += __builtin_amdgcn_s_memtime() - dg0;)
             }
-            const uint32_t col = 16u * tb + 1u + (lane & 15u);
             return col <= n ? __hip_atomic_load(seam_in + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
         };
-        int seam_next = reads_seam ? load_seam(0u) : 0;
+        int seam_grp = 0, seam_grp_next = reads_seam ? load_group(0u) : 0;
         for (uint32_t tb = 0; tb < nblk; ++tb) {
             const uint4 w = wnext;                       // base codes of columns 16tb+1 .. 16tb+16
-            wnext = refq[tb + 1];                        // prefetch (images are padded)
+            wnext = ref_words(tb + 1u);                  // prefetch (images are padded)
             const uint32_t t0 = 16u * tb;
             if (MODE == SWMI_MODE_WINMAX && (tb % SWMI_CK_BLOCKS) == 0u && tb > 0u) close_window(tb / SWMI_CK_BLOCKS - 1u);
             if ((MODE == SWMI_MODE_SCORE || MODE == SWMI_MODE_WINMAX) && (tb % SWMI_CK_BLOCKS) == 0u) {
@@ -524,19 +589,30 @@ __device__ __forceinline__ void fill_pair(const FillArgs &A, const PairDesc pd, 
                 ck[R * WAVE] = (uint32_t)S.nprev;
                 ck[(R + 1) * WAVE] = (uint32_t)S.rb;
             }
-            const int seamv = seam_next;
-            if (reads_seam) seam_next = load_seam(tb + 1u);
+            if (reads_seam && (tb & 3u) == 0u) {
+                SWMI_SD(const unsigned long long dg1 = __builtin_amdgcn_s_memtime();)
+                seam_grp = seam_grp_next;
+                SWMI_SD(asm volatile("s_waitcnt vmcnt(0)" : "+v"(seam_grp) :: "memory"); dg_grp += __builtin_amdgcn_s_memtime() - dg1;)
+                seam_grp_next = load_group(tb / 4u + 1u);
+            }
+            // lanes 0..15: the block's 16 values (0 in every lane of a strip without a seam above it)
+            const int seamv = reads_seam ? __builtin_amdgcn_ds_bpermute((int)(((tb & 3u) << 6) + ((lane & 15u) << 2)), seam_grp) : 0;
             const bool steady = (t0 + 1u >= lact) && (t0 + 15u < n);
+            // progress value p = "blocks 0 .. p-1 are complete", published every SWMI_PIPE_PUBLISH blocks, one block late
+            uint32_t *pub_slot = PIPE ? progress + s : nullptr;
+            const uint32_t pub_val = (PIPE && feeds_seam && tb > 0u && (tb % SWMI_PIPE_PUBLISH) == 0u) ? tb : 0u;
             if (steady)
                 fill_block16<R, ACGT, STRICT, MULTI, false, MODE, PIPE>(S, w, t0, lane, lane_eff, n, m, row0, gap, match, mismatch,
-                                                                        seamv, reads_seam, feeds_seam, seam_out, cells, ccap);
+                                                                        seamv, reads_seam, feeds_seam, seam_out, cells, ccap,
+                                                                        pub_slot, pub_val);
             else
                 fill_block16<R, ACGT, STRICT, MULTI, true, MODE, PIPE>(S, w, t0, lane, lane_eff, n, m, row0, gap, match, mismatch,
-                                                                       seamv, reads_seam, feeds_seam, seam_out, cells, ccap);
-            if (PIPE && feeds_seam) {
-                // this block's seam stores have left the CU (they are device-coherent stores): publish the progress
+                                                                       seamv, reads_seam, feeds_seam, seam_out, cells, ccap,
+                                                                       pub_slot, pub_val);
+            if (PIPE && feeds_seam && tb + 1u == nblk) {
+                // the strip is complete once its last seam stores have left the CU (they are device-coherent stores)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (lane == 0) __hip_atomic_store(progress + s, tb + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 0) __hip_atomic_store(progress + s, nblk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
 
             if (MODE == SWMI_MODE_FIELD) {
@@ -552,6 +628,14 @@ __device__ __forceinline__ void fill_pair(const FillArgs &A, const PairDesc pd, 
             }
         }
         if (MODE == SWMI_MODE_WINMAX) close_window((nblk - 1u) / SWMI_CK_BLOCKS);
+#ifdef SWMI_STRIP_DIAG
+        if (PIPE && A.dbg && lane == 0 && s < 2u) {
+            const unsigned long long tot = __builtin_amdgcn_s_memtime() - t_start;
+            // strip 0: {lifetime, waiting before publications}; strip 1: {lifetime, polls, waiting in polls, waiting for seam groups}
+            A.dbg[2 * pd.out_id + s] = s == 0u ? (tot << 32) | (S.dg_pub & 0xFFFFFFFFull)
+                                               : (tot << 40) | ((dg_polls & 0xFFull) << 32) | ((dg_poll & 0xFFFFull) << 16) | (dg_grp & 0xFFFFull);
+        }
+#endif
         // the tied-maximum test of the strip's last step is still pending (16 steps per block: its H is in S.h)
         if (S.ev_prev != 0) {
             handle_pending<R>(S, S.h, 16u * nblk - 1u, lane_eff, n, row0, m, cells, ccap);
@@ -849,8 +933,9 @@ sw_sweep_winmax_strips_kernel(const FillArgs A) {
     const SeqDesc qd = A.reads[pd.read_id];
     const bool acgt = rd.acgt && qd.acgt &&
                       SWMI_SCORES_FIT(A);
-    if (acgt) fill_pair<SWMI_RMAX, true, false, true, SWMI_MODE_WINMAX, true>(A, pd, lane, it.y);
-    else      fill_pair<SWMI_RMAX, false, false, true, SWMI_MODE_WINMAX, true>(A, pd, lane, it.y);
+    const uint32_t strip = __builtin_amdgcn_readfirstlane(it.y);     // wave-uniform: "does this strip feed a seam" stays scalar
+    if (acgt) fill_pair<SWMI_RMAX, true, false, true, SWMI_MODE_WINMAX, true>(A, pd, lane, strip);
+    else      fill_pair<SWMI_RMAX, false, false, true, SWMI_MODE_WINMAX, true>(A, pd, lane, strip);
 }
 
 // mode 1, few pairs with long references: one wavefront per COLUMN CHUNK of a pair (swmi_device.h: ColItem).  The
