@@ -229,8 +229,8 @@ struct swmi_batch {
         int mode = -1;
         uint64_t dir_words = 0, seam_words = 0;
         uint32_t max_path = 0, max_read = 0;
-        size_t n_strip_items = 0, n_col_items = 0;
-        uint64_t n_windows = 0;
+        size_t n_strip_items = 0, n_col_items = 0, n_strip_chunks = 0;
+        uint64_t n_windows = 0, seam_priv_words = 0;
         size_t n_res = 0;
         uint32_t res_lds_words = 0, res_ops_words = 0;
         int resident_opt = -1;
@@ -614,7 +614,9 @@ static int prepare_chunk(RunState &rs, const std::vector<Work> &work, size_t lo,
 
     // pair descriptors, direction-field and seam offsets
     std::vector<PairDesc> pd;
-    std::vector<uint2> strip_items;          // mode 1: (pair, strip) of every read longer than one strip, one wavefront each
+    std::vector<StripItem> strip_items;      // mode 1: (pair, column chunk, strip) of every read longer than one strip, one wavefront each
+    uint64_t seam_priv_words = 0;            // ... private seam rows of the column chunks among them (behind the shared rows in d_seam)
+    size_t n_strip_chunks = 0;               // ... and how many chunk sweeps (0: every multi-strip pair in one)
     std::vector<ColItem> col_items;          // mode 1: column chunks of single-strip pairs when the launch has few pairs
     uint64_t dir_words = 0, seam_words = 0;
     uint32_t max_path = 0, max_read = 0;
@@ -638,6 +640,7 @@ static int prepare_chunk(RunState &rs, const std::vector<Work> &work, size_t lo,
     if (prepared) {
         dir_words = pr.dir_words; seam_words = pr.seam_words; max_path = pr.max_path; max_read = pr.max_read;
         n_strip_items = pr.n_strip_items; n_col_items = pr.n_col_items; n_windows = pr.n_windows;
+        seam_priv_words = pr.seam_priv_words; n_strip_chunks = pr.n_strip_chunks;
         n_res = pr.n_res; res_lds_words = pr.res_lds_words; res_ops_words = pr.res_ops_words;
         n_tf = pr.n_tf; tf_max_m = pr.tf_max_m; tf_max_n = pr.tf_max_n; tf_max_path = pr.tf_max_path;
     } else {
@@ -721,8 +724,53 @@ static int prepare_chunk(RunState &rs, const std::vector<Work> &work, size_t lo,
         } else if (b->eff_mode == 1 && m_ > 64u * SWMI_RMAX && strip_items.size() < (1u << 30)) {
             const uint32_t strips = (m_ + 64u * SWMI_RMAX - 1u) / (64u * SWMI_RMAX);
             d.pad = (uint32_t)strip_items.size();
-            if (ctx->dbg_reverse_strips) for (uint32_t st = strips; st-- > 0;) strip_items.push_back(make_uint2((uint32_t)k, st));
-            else                         for (uint32_t st = 0; st < strips; st++) strip_items.push_back(make_uint2((uint32_t)k, st));
+            auto push_strips = [&](StripItem it) {
+                it.pair = (uint32_t)k;
+                it.prog = (uint32_t)strip_items.size();
+                it.pad = 0;
+                if (ctx->dbg_reverse_strips) for (uint32_t st = strips; st-- > 0;) { it.strip = st; strip_items.push_back(it); }
+                else                         for (uint32_t st = 0; st < strips; st++) { it.strip = st; strip_items.push_back(it); }
+            };
+            // Column chunks of a multi-strip pair (swmi_device.h: StripItem): the halo argument holds for the whole read, so
+            // a chunk is a strip pipeline of its own over [col0, end of its windows], all strips starting from zero.  The
+            // halo is long (2.25 m columns at the default scores): a chunk's body may be as short as a quarter of it -- the
+            // launch has SIMDs to spare, and what counts is the length of the longest chain.
+            uint64_t chunks = 1;
+            const uint64_t wblocks = ((uint64_t)n_ + 63u + 15u) / 16u;
+            const uint32_t n_ck = (uint32_t)((wblocks + SWMI_CK_BLOCKS - 1u) / SWMI_CK_BLOCKS);
+            const uint32_t step_w = 16u * SWMI_CK_BLOCKS;
+            const uint64_t span = (uint64_t)m_ + (uint64_t)(P.match > 0 ? P.match : 0) * m_ / (uint64_t)(P.gap < 0 ? -(int64_t)P.gap : 1) + 1;
+            if (cols_possible) {                                   // (any symbols: the strip kernel has both cell streams)
+                const uint64_t budget = ctx->col_chunks > 1 ? ctx->col_chunks : chunk_budget / strips;
+                chunks = std::min<uint64_t>(budget, n_ / std::max<uint64_t>((span + 64) / 4, 256));
+                chunks = std::min<uint64_t>(chunks, n_ck);
+                if (chunks < 2) chunks = 1;
+            }
+            if (chunks == 1) {
+                StripItem it{};
+                it.col0 = 0; it.g_lo = 0; it.g_hi = 0xFFFFFFFFu; it.priv_stride = 0; it.priv_off = 0;
+                push_strips(it);
+            } else {
+                const uint32_t wpc = (uint32_t)((n_ck + chunks - 1) / chunks);   // windows per chunk
+                for (uint32_t g_lo = 0; g_lo < n_ck; g_lo += wpc) {
+                    StripItem it{};
+                    it.g_lo = g_lo;
+                    it.g_hi = std::min(g_lo + wpc, n_ck);
+                    if (it.g_hi < n_ck && (uint64_t)it.g_hi * step_w > n_) it.g_hi = n_ck;
+                    const int64_t c0 = (int64_t)g_lo * step_w - 64 - (int64_t)span - 1;
+                    it.col0 = g_lo == 0 || c0 <= 0 ? 0u : (uint32_t)(c0 / step_w * step_w);
+                    // strip 0 runs furthest: 64 steps per strip below it past the chunk's last window, or to the reference's end
+                    const uint64_t ext0 = (uint64_t)it.g_hi * step_w - it.col0 + 64ull * (strips - 1u);
+                    const uint64_t n0 = it.g_hi < n_ck ? std::min<uint64_t>(n_ - it.col0, ext0) : n_ - it.col0;
+                    it.priv_stride = (uint32_t)((n0 + 1 + 15) & ~15ull);
+                    it.priv_off = seam_priv_words;                                  // (+ the shared rows of the launch: below)
+                    seam_priv_words += (uint64_t)(strips - 1u) * it.priv_stride;
+                    if (it.g_hi == n_ck) it.g_hi = 0xFFFFFFFFu;                     // (the pair's last chunk: every window from g_lo on)
+                    push_strips(it);
+                    n_strip_chunks++;
+                    if (it.g_hi == 0xFFFFFFFFu) break;
+                }
+            }
         } else if (cols_possible && chunk_budget > 1 && m_ <= 64u * SWMI_RMAX && b->read_desc[d.read_id].acgt && b->ref_desc[d.ref_id].acgt) {
             const uint64_t span = (uint64_t)m_ + (uint64_t)P.match * m_ / (uint64_t)(-(int64_t)P.gap) + 1;   // columns a path can span
             const uint64_t wblocks = ((uint64_t)n_ + 63u + 15u) / 16u;
@@ -784,6 +832,8 @@ static int prepare_chunk(RunState &rs, const std::vector<Work> &work, size_t lo,
         }
     }
     if (b->eff_mode == 1) win_off[np] = (uint32_t)std::min<uint64_t>(n_windows, 0xFFFFFFFFu);
+    for (StripItem &it : strip_items)
+        if (it.priv_stride) it.priv_off += seam_words;
     }
     const auto p1 = std::chrono::steady_clock::now();
     if (!prepared && b->eff_mode == 1) {
@@ -793,9 +843,9 @@ static int prepare_chunk(RunState &rs, const std::vector<Work> &work, size_t lo,
     }
     if ((rc = b->d_pairs.reserve(np * sizeof(PairDesc)))) return rc;
     if (!prepared && !strip_items.empty()) {
-        if ((rc = b->d_strip_items.reserve(strip_items.size() * sizeof(uint2)))) return rc;
+        if ((rc = b->d_strip_items.reserve(strip_items.size() * sizeof(StripItem)))) return rc;
         if ((rc = b->d_progress.reserve(strip_items.size() * sizeof(uint32_t)))) return rc;
-        HIP_TRY(hipMemcpyAsync(b->d_strip_items.p, strip_items.data(), strip_items.size() * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(b->d_strip_items.p, strip_items.data(), strip_items.size() * sizeof(StripItem), hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));      // strip_items is a local
     }
     if (!prepared && !res_items.empty()) {
@@ -814,7 +864,7 @@ static int prepare_chunk(RunState &rs, const std::vector<Work> &work, size_t lo,
         HIP_TRY(hipStreamSynchronize(ctx->stream));      // col_items is a local
     }
     if ((rc = b->d_dir.reserve(std::max<uint64_t>(dir_words, 1) * 4))) return rc;
-    if ((rc = b->d_seam.reserve(std::max<uint64_t>(seam_words, 1) * 4))) return rc;
+    if ((rc = b->d_seam.reserve(std::max<uint64_t>(seam_words + seam_priv_words, 1) * 4))) return rc;
     // repeated runs of one batch schedule the same pairs: skip the H2D copy when nothing changed
     if (!prepared && (b->pairs_dev_ptr != b->d_pairs.p || b->pairs_on_device.size() != np * sizeof(PairDesc) ||
         memcmp(b->pairs_on_device.data(), pd.data(), np * sizeof(PairDesc)) != 0)) {
@@ -828,6 +878,7 @@ static int prepare_chunk(RunState &rs, const std::vector<Work> &work, size_t lo,
         pr.lo = lo; pr.hi = hi; pr.work = (const void *)work.data(); pr.params = b->params; pr.mode = b->eff_mode;
         pr.dir_words = dir_words; pr.seam_words = seam_words; pr.max_path = max_path; pr.max_read = max_read;
         pr.n_strip_items = n_strip_items; pr.n_col_items = n_col_items; pr.n_windows = n_windows;
+        pr.seam_priv_words = seam_priv_words; pr.n_strip_chunks = n_strip_chunks;
         pr.n_res = n_res; pr.res_lds_words = res_lds_words; pr.res_ops_words = res_ops_words;
         pr.resident_opt = ctx->resident; pr.exact = cells_exact != nullptr;
         pr.tfused_opt = ctx->tfused; pr.n_tf = n_tf; pr.tf_max_m = tf_max_m; pr.tf_max_n = tf_max_n; pr.tf_max_path = tf_max_path;
@@ -1054,12 +1105,12 @@ static int run_chunk(RunState &rs, const std::vector<Work> &work, size_t lo, siz
         fa.mode = b->eff_mode;
         const bool pipe = n_strip_items && !rs.one_wave_sweep;
         fa.skip_multi = pipe ? 1u : 0u;
-        fa.strip_items = pipe ? b->d_strip_items.as<uint2>() : nullptr;
+        fa.strip_items = pipe ? b->d_strip_items.as<StripItem>() : nullptr;
         fa.progress = pipe ? b->d_progress.as<uint32_t>() : nullptr;
         fa.n_strip_items = pipe ? (uint32_t)n_strip_items : 0u;
         fa.err_host = (uint32_t *)ctx->h_err.dp;
         fa.pad3 = 0;
-        if (attempt == 0) b->timing.col_chunks += (uint32_t)n_col_items;
+        if (attempt == 0) b->timing.col_chunks += (uint32_t)n_col_items + (pipe ? (uint32_t)pr.n_strip_chunks : 0u);
         fa.col_items = n_col_items ? b->d_col_items.as<ColItem>() : nullptr;
         fa.n_col_items = (uint32_t)n_col_items;
         fa.strip_spins = ctx->dbg_strip_spins;

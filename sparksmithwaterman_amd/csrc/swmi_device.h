@@ -58,7 +58,7 @@ struct PairDesc {
     uint32_t ref_id;
     uint32_t read_id;
     uint32_t out_id;      // index into out[] / cells[] (the pair's position in the batch)
-    uint32_t pad;         // mode 1, pairs of several strips: index of the pair's first entry in FillArgs.progress
+    uint32_t pad;         // flags below (mode 1)
     uint64_t dir_off;     // dword offset of this pair's direction field in dir[]
     uint64_t seam_off;    // dword offset of the strip-seam rows, n+1 int32 per strip (multi-strip pairs only)
 };
@@ -76,6 +76,21 @@ struct ColItem {
     uint32_t pair;        // index into FillArgs.pairs
     uint32_t col0;
     uint32_t g_lo, g_hi;
+};
+
+// One wavefront of the strip pipeline (sw_sweep_winmax_strips_kernel): strip `strip` of pair `pair`, for the whole reference
+// (col0 = 0, g_lo = 0, g_hi >= the strip's windows) or for ONE COLUMN CHUNK of it -- ColItem's rule holds for every strip as
+// long as the seam rows of the halo are swept too: all strips of a chunk start at column col0 + 1 from a zero state, the
+// chunk owns the checkpoint windows g_lo .. g_hi-1 of every strip, and strip s runs 64 steps further than strip s+1 (whose
+// lane 0 needs the seam that far).  A chunk keeps PRIVATE seam rows for its own strips (its halo values are not exact) and
+// writes the columns it owns into the pair's shared seam rows, which the traceback's replay reads.
+struct StripItem {
+    uint32_t pair, strip;
+    uint32_t col0, g_lo, g_hi;
+    uint32_t prog;          // index of the first progress slot of this (pair, chunk): + strip
+    uint32_t priv_stride;   // dwords per private seam row (0: not chunked, the strips hand over through the shared rows)
+    uint32_t pad;
+    uint64_t priv_off;      // dword offset of the chunk's private seam rows in seam[]: row s at priv_off + s * priv_stride
 };
 
 struct PairOut {
@@ -133,7 +148,7 @@ struct FillArgs {
     uint32_t        mode;        // 0 = direction field in HBM, 1 = checkpoints + window maxima, 2 = checkpoints + event-tracked maxima
     uint32_t        skip_multi;  // mode 1: the pairs of several strips are left to sw_sweep_winmax_strips_kernel
     // mode 1, reads longer than one strip: one wavefront per STRIP, pipelined through the seam rows
-    const uint2    *strip_items; // {pair index of this launch, strip}, the strips of a pair consecutive and ascending
+    const StripItem *strip_items; // the strips of a (pair, column chunk) consecutive and ascending
     uint32_t       *progress;    // per strip item: 16-step blocks finished (the item's index is PairDesc.pad + strip)
     uint32_t        n_strip_items;
     uint32_t        pad3;

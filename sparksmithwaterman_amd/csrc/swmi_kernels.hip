@@ -305,7 +305,8 @@ __device__ __forceinline__ void fill_block16(FillState<R> &S, const uint4 w, con
                                              const int seamv, const bool reads_seam, const bool feeds_seam,
                                              int32_t *__restrict__ seam_out,
                                              uint2 *__restrict__ cells, const uint32_t ccap,
-                                             uint32_t *pub_slot = nullptr, const uint32_t pub_val = 0u) {
+                                             uint32_t *pub_slot = nullptr, const uint32_t pub_val = 0u,
+                                             int32_t *__restrict__ seam_sh = nullptr, const uint32_t own_lo = 0u, const uint32_t own_hi = 0u) {
     constexpr bool DIRS = MODE == SWMI_MODE_FIELD || MODE == SWMI_MODE_REPLAY || MODE == SWMI_MODE_DETECT;
     constexpr bool TRACK = MODE == SWMI_MODE_FIELD || MODE == SWMI_MODE_SCORE;     // deferred tied-maximum events
     constexpr bool LMAX = MODE == SWMI_MODE_WINMAX;                                  // per-lane running maximum only
@@ -369,6 +370,7 @@ __device__ __forceinline__ void fill_block16(FillState<R> &S, const uint4 w, con
                 if (MULTI && FEEDS && feeds_seam && lane == WAVE - 1) {
                     if (PIPE) __hip_atomic_store(seam_out + c0 + 1, hout[R - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     else      seam_out[c0 + 1] = hout[R - 1];
+                    if (PIPE && seam_sh && c0 + 1u > own_lo && c0 + 1u <= own_hi) seam_sh[c0 + 1] = hout[R - 1];   // (column chunk: the columns it owns)
                 }
             } else {
 #pragma unroll
@@ -430,9 +432,11 @@ __device__ __forceinline__ void fill_block16(FillState<R> &S, const uint4 w, con
     if (MULTI && FEEDS && !PRED && feeds_seam && lane < 16u) {
         // a steady block of a strip that feeds a seam has all 64 lanes on rows: lane 63 was on column t0 + s - 62 (1-based)
         // at step s.  PIPE: another wavefront (possibly on another XCD) is already reading this row: device-coherent store
-        int32_t *dst = seam_out + (t0 - (WAVE - 2u)) + lane;
+        const uint32_t col = t0 - (WAVE - 2u) + lane;
+        int32_t *dst = seam_out + col;
         if (PIPE) __hip_atomic_store(dst, seam_acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else      *dst = seam_acc;
+        if (PIPE && seam_sh && col > own_lo && col <= own_hi) seam_sh[col] = seam_acc;
     }
 }
 
@@ -467,18 +471,24 @@ __device__ __forceinline__ StripGeom strip_geom(uint32_t m, uint32_t n, uint32_t
 // 10 kbp read is swept in about the time of ONE strip instead of 40.
 #define SWMI_PIPE_PUBLISH 4u      // blocks between two publications of a strip's progress
 template <int R, bool ACGT, bool STRICT, bool MULTI, int MODE, bool PIPE = false>
-__device__ __forceinline__ void fill_pair(const FillArgs &A, const PairDesc pd, const uint32_t lane, const uint32_t my_strip = 0u) {
+__device__ __forceinline__ void fill_pair(const FillArgs &A, const PairDesc pd, const uint32_t lane, const uint32_t my_strip = 0u,
+                                          const StripItem *item = nullptr) {
     const SeqDesc rd = A.refs[pd.ref_id];
     const SeqDesc qd = A.reads[pd.read_id];
     // PIPE: the geometry in scalar registers, so that the block counter is one and the reference words can come through
     // the scalar cache: a vector load's s_waitcnt vmcnt also waits for every store issued before it, the device-scope seam
     // stores among them
-    const uint32_t n = PIPE ? uni(rd.len) : rd.len, m = PIPE ? uni(qd.len) : qd.len;
-    const uint32_t *__restrict__ refw = A.seqw + (PIPE ? uni(rd.boff) : rd.boff);
+    const uint32_t n_full = PIPE ? uni(rd.len) : rd.len, m = PIPE ? uni(qd.len) : qd.len;
+    // PIPE, column chunk (StripItem): the sweep starts at reference column col0 + 1 from a zero state and owns the windows
+    // g_lo .. g_hi-1; the whole reference is the chunk {0, 0, all windows}
+    const uint32_t col0 = PIPE ? uni(item->col0) : 0u;
+    const uint32_t g_lo = PIPE ? uni(item->g_lo) : 0u, g_hi = PIPE ? uni(item->g_hi) : 0xFFFFFFFFu;
+    const uint32_t priv_stride = PIPE ? uni(item->priv_stride) : 0u;
+    const uint32_t *__restrict__ refw = A.seqw + (PIPE ? uni(rd.boff) + (col0 >> 2) : rd.boff);
     const uint32_t *__restrict__ readw = A.seqw + qd.boff;
     const int match = A.match, mismatch = A.mismatch, gap = A.gap;
     constexpr uint32_t HMODE = MODE == SWMI_MODE_FIELD ? 0u : (MODE == SWMI_MODE_WINMAX ? 1u : 2u);
-    const StripGeom G = strip_geom<R>(m, n, HMODE);
+    const StripGeom G = strip_geom<R>(m, n_full, HMODE);
     int pair_max = 0;        // WINMAX: maximum over the finished windows
 
     const uint64_t cbase = A.cells_off ? A.cells_off[pd.out_id] : (uint64_t)pd.out_id * A.cell_cap;
@@ -497,12 +507,21 @@ __device__ __forceinline__ void fill_pair(const FillArgs &A, const PairDesc pd, 
     const unsigned long long t_start = A.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
 
     const uint32_t s_begin = PIPE ? my_strip : 0u, s_end = PIPE ? my_strip + 1u : G.n_strips;
-    uint32_t *__restrict__ progress = PIPE ? A.progress + pd.pad : nullptr;
+    uint32_t *__restrict__ progress = PIPE ? A.progress + uni(item->prog) : nullptr;
     for (uint32_t s = s_begin; s < s_end; ++s) {
         const uint32_t row0 = s * G.rps + lane * R;        // 0-based first row of this lane
         const uint32_t rows_left = m - s * G.rps;
         const uint32_t lact = rows_left >= G.rps ? WAVE : (rows_left + R - 1) / R;   // lanes holding rows
-        const uint32_t T = n + lact - 1;                 // steps of this strip
+        // columns this strip sweeps (from col0 + 1 on).  A column chunk that is not the pair's last ends after its last
+        // window -- 64 steps later per strip below this one, whose lane 0 needs the seam that far -- unless that is past
+        // the reference's end
+        uint32_t n = n_full - col0;
+        bool truncated = false;
+        if (PIPE && g_hi < G.n_ck) {
+            const uint32_t ext = 16u * SWMI_CK_BLOCKS * g_hi - col0 + WAVE * (G.n_strips - 1u - s);
+            if (ext < n) { n = ext; truncated = true; }
+        }
+        const uint32_t T = truncated ? n : n + lact - 1; // steps of this strip
         const uint32_t lane_eff = lane < lact ? lane : 0x40000000u;   // lanes without rows are never in range
         setup_rows<R, ACGT>(S, readw, row0, m, match, mismatch);
         S.lmax = -1;
@@ -519,11 +538,21 @@ __device__ __forceinline__ void fill_pair(const FillArgs &A, const PairDesc pd, 
         };
         const int32_t *seam_in = nullptr;
         int32_t *seam_out = nullptr;
+        int32_t *seam_sh = nullptr;                                   // column chunk: the pair's shared row, for the columns the chunk owns
         if (MULTI) {
             int32_t *sb = A.seam + pd.seam_off;                       // row s = H of the strip's last read row
-            seam_in = sb + (uint64_t)(s > 0 ? s - 1 : 0) * (n + 1);
-            seam_out = sb + (uint64_t)s * (n + 1);
+            seam_in = sb + (uint64_t)(s > 0 ? s - 1 : 0) * (n_full + 1);
+            seam_out = sb + (uint64_t)s * (n_full + 1);
+            if (PIPE && priv_stride) {
+                int32_t *pb = A.seam + item->priv_off;                // the chunk's own rows, indexed by local column
+                seam_sh = seam_out + col0;
+                seam_in = pb + (uint64_t)(s > 0 ? s - 1 : 0) * priv_stride;
+                seam_out = pb + (uint64_t)s * priv_stride;
+            }
         }
+        const uint32_t step_w = 16u * SWMI_CK_BLOCKS;
+        const uint32_t own_lo = step_w * g_lo > col0 ? step_w * g_lo - col0 : 0u;                  // owned local columns: own_lo < c <= own_hi
+        const uint32_t own_hi = g_hi < G.n_ck ? step_w * g_hi - col0 : 0xFFFFFFFFu;
         const bool feeds_seam = MULTI && (s + 1 < G.n_strips);
         const bool reads_seam = MULTI && (s > 0);
 
@@ -543,7 +572,11 @@ __device__ __forceinline__ void fill_pair(const FillArgs &A, const PairDesc pd, 
         // blocks and the polled value is kept, so a consumer that is behind does not poll at all: ~24 polls per 254 blocks
         // (a poll and a wait for the stores' acknowledgements per block: 0.415 ms at 257 x 4000, this way 0.357;
         // profiles/r03/strip_pipeline.md).
-        const uint32_t nblk_prod = (n + WAVE - 1u + 15u) / 16u;
+        uint32_t nblk_prod = (n_full - col0 + WAVE - 1u + 15u) / 16u;
+        if (truncated || (PIPE && g_hi < G.n_ck)) {
+            const uint32_t ext_p = 16u * SWMI_CK_BLOCKS * g_hi - col0 + WAVE * (G.n_strips - s);      // (strip s-1's extent)
+            if (ext_p < n_full - col0) nblk_prod = ext_p / 16u;
+        }
         bool gave_up = false;
         uint32_t prod_seen = 0u;
 #ifdef SWMI_STRIP_DIAG
@@ -580,10 +613,14 @@ __device__ __forceinline__ void fill_pair(const FillArgs &A, const PairDesc pd, 
             const uint4 w = wnext;                       // base codes of columns 16tb+1 .. 16tb+16
             wnext = ref_words(tb + 1u);                  // prefetch (images are padded)
             const uint32_t t0 = 16u * tb;
-            if (MODE == SWMI_MODE_WINMAX && (tb % SWMI_CK_BLOCKS) == 0u && tb > 0u) close_window(tb / SWMI_CK_BLOCKS - 1u);
-            if ((MODE == SWMI_MODE_SCORE || MODE == SWMI_MODE_WINMAX) && (tb % SWMI_CK_BLOCKS) == 0u) {
+            const uint32_t tbg = tb + (col0 >> 4);       // the block's number in the pair's own sweep (col0 is a multiple of 32)
+            const uint32_t gw = tbg / SWMI_CK_BLOCKS;    // ... and its window
+            if (MODE == SWMI_MODE_WINMAX && (tbg % SWMI_CK_BLOCKS) == 0u && tb > 0u) {
+                if (gw > g_lo && gw <= g_hi) close_window(gw - 1u); else S.lmax = -1;
+            }
+            if ((MODE == SWMI_MODE_SCORE || MODE == SWMI_MODE_WINMAX) && (tbg % SWMI_CK_BLOCKS) == 0u && gw >= g_lo && gw < g_hi) {
                 // checkpoint: everything a replay of steps t0.. needs from this lane ([ck][slot][lane], 256 B stores)
-                uint32_t *__restrict__ ck = wsp + (uint64_t)(tb / SWMI_CK_BLOCKS) * (R + 2) * WAVE;
+                uint32_t *__restrict__ ck = wsp + (uint64_t)gw * (R + 2) * WAVE;
 #pragma unroll
                 for (int k = 0; k < R; ++k) ck[k * WAVE] = (uint32_t)S.h[k];
                 ck[R * WAVE] = (uint32_t)S.nprev;
@@ -597,18 +634,18 @@ __device__ __forceinline__ void fill_pair(const FillArgs &A, const PairDesc pd, 
             }
             // lanes 0..15: the block's 16 values (0 in every lane of a strip without a seam above it)
             const int seamv = reads_seam ? __builtin_amdgcn_ds_bpermute((int)(((tb & 3u) << 6) + ((lane & 15u) << 2)), seam_grp) : 0;
-            const bool steady = (t0 + 1u >= lact) && (t0 + 15u < n);
+            const bool steady = (t0 + 1u >= lact) && (t0 + 15u < n);     // (a truncated strip never leaves the reference)
             // progress value p = "blocks 0 .. p-1 are complete", published every SWMI_PIPE_PUBLISH blocks, one block late
             uint32_t *pub_slot = PIPE ? progress + s : nullptr;
             const uint32_t pub_val = (PIPE && feeds_seam && tb > 0u && (tb % SWMI_PIPE_PUBLISH) == 0u) ? tb : 0u;
             if (steady)
                 fill_block16<R, ACGT, STRICT, MULTI, false, MODE, PIPE>(S, w, t0, lane, lane_eff, n, m, row0, gap, match, mismatch,
                                                                         seamv, reads_seam, feeds_seam, seam_out, cells, ccap,
-                                                                        pub_slot, pub_val);
+                                                                        pub_slot, pub_val, seam_sh, own_lo, own_hi);
             else
                 fill_block16<R, ACGT, STRICT, MULTI, true, MODE, PIPE>(S, w, t0, lane, lane_eff, n, m, row0, gap, match, mismatch,
                                                                        seamv, reads_seam, feeds_seam, seam_out, cells, ccap,
-                                                                       pub_slot, pub_val);
+                                                                       pub_slot, pub_val, seam_sh, own_lo, own_hi);
             if (PIPE && feeds_seam && tb + 1u == nblk) {
                 // the strip is complete once its last seam stores have left the CU (they are device-coherent stores)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -627,7 +664,10 @@ __device__ __forceinline__ void fill_pair(const FillArgs &A, const PairDesc pd, 
                 }
             }
         }
-        if (MODE == SWMI_MODE_WINMAX) close_window((nblk - 1u) / SWMI_CK_BLOCKS);
+        if (MODE == SWMI_MODE_WINMAX) {
+            const uint32_t gl = (nblk - 1u + (col0 >> 4)) / SWMI_CK_BLOCKS;
+            if (gl >= g_lo && gl < g_hi) close_window(gl);
+        }
 #ifdef SWMI_STRIP_DIAG
         if (PIPE && A.dbg && lane == 0 && s < 2u) {
             const unsigned long long tot = __builtin_amdgcn_s_memtime() - t_start;
@@ -654,9 +694,9 @@ __device__ __forceinline__ void fill_pair(const FillArgs &A, const PairDesc pd, 
         PairOut o;
         if (MODE == SWMI_MODE_WINMAX) {
             // the cells holding the maximum are listed by the traceback kernel (n_cells follows there)
-            if (pair_max <= 0) { o.score = 0; o.flags = SWMI_F_DEGENERATE; o.n_cells = (uint64_t)m * n; }
+            if (pair_max <= 0) { o.score = 0; o.flags = SWMI_F_DEGENERATE; o.n_cells = (uint64_t)m * n_full; }
             else               { o.score = pair_max; o.flags = 0u; o.n_cells = 0; }
-        } else if (S.cnt == 0) { o.score = 0; o.flags = SWMI_F_DEGENERATE; o.n_cells = (uint64_t)m * n; }
+        } else if (S.cnt == 0) { o.score = 0; o.flags = SWMI_F_DEGENERATE; o.n_cells = (uint64_t)m * n_full; }
         else            { o.score = S.thr; o.flags = S.cnt > ccap ? SWMI_F_CELL_OVF : 0u; o.n_cells = S.cnt; }
         A.out[pd.out_id] = o;
         if (A.dbg) {
@@ -927,15 +967,15 @@ sw_sweep_winmax_strips_kernel(const FillArgs A) {
     const uint32_t item = blockIdx.x * FILL_WAVES + (threadIdx.x >> 6);
     if (item >= A.n_strip_items) return;
     const uint32_t lane = threadIdx.x & 63u;
-    const uint2 it = A.strip_items[item];
-    const PairDesc pd = A.pairs[it.x];
+    const StripItem *it = A.strip_items + item;
+    const PairDesc pd = A.pairs[it->pair];
     const SeqDesc rd = A.refs[pd.ref_id];
     const SeqDesc qd = A.reads[pd.read_id];
     const bool acgt = rd.acgt && qd.acgt &&
                       SWMI_SCORES_FIT(A);
-    const uint32_t strip = __builtin_amdgcn_readfirstlane(it.y);     // wave-uniform: "does this strip feed a seam" stays scalar
-    if (acgt) fill_pair<SWMI_RMAX, true, false, true, SWMI_MODE_WINMAX, true>(A, pd, lane, strip);
-    else      fill_pair<SWMI_RMAX, false, false, true, SWMI_MODE_WINMAX, true>(A, pd, lane, strip);
+    const uint32_t strip = __builtin_amdgcn_readfirstlane(it->strip);     // wave-uniform: "does this strip feed a seam" stays scalar
+    if (acgt) fill_pair<SWMI_RMAX, true, false, true, SWMI_MODE_WINMAX, true>(A, pd, lane, strip, it);
+    else      fill_pair<SWMI_RMAX, false, false, true, SWMI_MODE_WINMAX, true>(A, pd, lane, strip, it);
 }
 
 // mode 1, few pairs with long references: one wavefront per COLUMN CHUNK of a pair (swmi_device.h: ColItem).  The

@@ -14,7 +14,7 @@ ctx.set_option("profiling", 1)
 for opt in sys.argv[1:]:
     k, _, v = opt.partition("=")
     ctx.set_option(k, int(v))
-print("L     wall ms  sweep ms  traceback ms  alignments  mean path")
+print("L     wall ms  sweep ms  traceback ms  alignments  mean path  chunk sweeps")
 for L in (100, 200, 256, 257, 300, 400, 500):
     b = ctx.upload([REF * 50], [(READ_80 * 7)[:L]] * 5)
     b.run()
@@ -27,6 +27,7 @@ for L in (100, 200, 256, 257, 300, 400, 500):
             best = (dt, b.timing())
     n_aln = sum(b.n_alignments(p)[0] for p in range(5))
     na, nc = b.materialise_all()
-    print("%-5d %.3f    %.3f     %.3f         %d         %.0f" % (L, best[0] * 1e3, best[1].fill_ms, best[1].traceback_ms, n_aln, nc / 2 / max(na, 1)))
+    print("%-5d %.3f    %.3f     %.3f         %d         %.0f        %d" % (L, best[0] * 1e3, best[1].fill_ms, best[1].traceback_ms, n_aln,
+                                                                        nc / 2 / max(na, 1), best[1].col_chunks))
     b.free()
 ctx.close()

@@ -350,10 +350,16 @@ def test_column_chunks_of_long_references(ctx):
     """Few pairs, long references: the mode-1 sweep of a pair is cut into column chunks, one wavefront each, every chunk
     re-deriving its left context from a halo no positive-score path can span (swmi_device.h: ColItem).  Checked against
     the oracle in full -- scores, every tied maximum, every alignment -- for forced chunk counts and the automatic one,
-    random and periodic references (EngineerData.java:118: REF repeated, one tied maximum per period)."""
+    random and periodic references (EngineerData.java:118: REF repeated, one tied maximum per period), reads of one strip and
+    of two and three (EngineerData.java:87-104: read lengths up to 500)."""
     rng = random.Random(42)
     rnd = ["".join(rng.choice("ACGT") for _ in range(n)) for n in (9000, 20011, 4097)]
     reads = [rnd[0][4000:4150], rnd[1][10:90], READ_80, rnd[1][19000:19250]]
+    # reads of several strips (> 256 rows): every column chunk is a strip pipeline of its own (swmi_device.h: StripItem) --
+    # 520 rows cut out of a reference, 700 rows (three strips) with substitutions and a gap, EngineerData's periodic read
+    long3 = rnd[1][5000:5300] + "A" + rnd[1][5300:5340] + rnd[1][5350:5700]
+    long3 = "".join("ACGT"[("ACGT".index(c) + 1) % 4] if i % 41 == 0 else c for i, c in enumerate(long3))
+    reads += [rnd[0][2000:2520], long3, (READ_80 * 7)[:300]]
     refs = rnd + [REF * 130, "T" * 5000 + reads[0] + "T" * 3000 + reads[0][:120] + "T" * 900]
     for chunks in (0, 2, 7, 64, 1):
         ctx.set_option("col_chunks", chunks)
