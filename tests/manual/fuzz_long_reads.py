@@ -49,6 +49,11 @@ while time.time() < t_end:
     tie = rng.randint(0, 1)
     chunks = rng.choice([0, 0, 0, 2, 5, 17, 64, 1])
     ctx.set_option("col_chunks", chunks)
+    # the other pipelines share the strip code (fill_pair / fill_block16): the direction field (0), event-tracked maxima (2),
+    # the fused and the split traceback, results by copy instead of zero-copy
+    ctx.set_option("mode", rng.choice([-1, -1, 1, 1, 0, 2]))
+    ctx.set_option("tb_split", rng.choice([-1, -1, 0, 1]))
+    ctx.set_option("zero_copy", rng.choice([1, 1, 0]))
     b = ctx.upload(refs, reads).run(sw.make_params(scores, ("a", "i", "d", "-"), tie))
     chunked += 1 if b.timing().col_chunks else 0
     for r, ref in enumerate(refs):
