@@ -469,7 +469,7 @@ __device__ __forceinline__ StripGeom strip_geom(uint32_t m, uint32_t n, uint32_t
 // PIPE (mode 1, MULTI): this wavefront sweeps only strip `my_strip`; the wavefront of strip s-1 runs a few blocks ahead
 // and publishes its progress, the one of strip s+1 follows -- a systolic pipeline of strips over wavefronts, so a
 // 10 kbp read is swept in about the time of ONE strip instead of 40.
-#define SWMI_PIPE_PUBLISH 4u      // blocks between two publications of a strip's progress
+#define SWMI_PIPE_PUBLISH 2u      // blocks between two publications of a strip's progress
 template <int R, bool ACGT, bool STRICT, bool MULTI, int MODE, bool PIPE = false>
 __device__ __forceinline__ void fill_pair(const FillArgs &A, const PairDesc pd, const uint32_t lane, const uint32_t my_strip = 0u,
                                           const StripItem *item = nullptr) {
@@ -569,9 +569,10 @@ __device__ __forceinline__ void fill_pair(const FillArgs &A, const PairDesc pd, 
         // group register with one ds_bpermute.
         // PIPE: column c of the seam row is stored by the producer's lane 63 at step c + 62, so the columns of block x are
         // complete when the producer has finished block x + 4; the producer publishes its progress every SWMI_PIPE_PUBLISH
-        // blocks and the polled value is kept, so a consumer that is behind does not poll at all: ~24 polls per 254 blocks
-        // (a poll and a wait for the stores' acknowledgements per block: 0.415 ms at 257 x 4000, this way 0.357;
-        // profiles/r03/strip_pipeline.md).
+        // blocks and the polled value is kept, so a consumer that is behind does not poll at all (a poll and a wait for
+        // the stores' acknowledgements per block: 0.415 ms at 257 x 4000; every 4 blocks, 24 polls per 254 blocks: 0.357;
+        // every 2 blocks with the next group asked for 2 blocks ahead instead of 4 costs two strips 2 % and gains a
+        // 40-strip pipeline 3 %: profiles/r03/strip_pipeline.md).
         uint32_t nblk_prod = (n_full - col0 + WAVE - 1u + 15u) / 16u;
         if (truncated || (PIPE && g_hi < G.n_ck)) {
             const uint32_t ext_p = 16u * SWMI_CK_BLOCKS * g_hi - col0 + WAVE * (G.n_strips - s);      // (strip s-1's extent)
@@ -630,8 +631,10 @@ __device__ __forceinline__ void fill_pair(const FillArgs &A, const PairDesc pd, 
                 SWMI_SD(const unsigned long long dg1 = __builtin_amdgcn_s_memtime();)
                 seam_grp = seam_grp_next;
                 SWMI_SD(asm volatile("s_waitcnt vmcnt(0)" : "+v"(seam_grp) :: "memory"); dg_grp += __builtin_amdgcn_s_memtime() - dg1;)
-                seam_grp_next = load_group(tb / 4u + 1u);
             }
+            // the next group is asked for two blocks before it is needed, not four: every block of distance is a block a
+            // strip trails the one above it, and a 10 kbp read is a pipeline of 40 strips
+            if (reads_seam && (tb & 3u) == 2u) seam_grp_next = load_group(tb / 4u + 1u);
             // lanes 0..15: the block's 16 values (0 in every lane of a strip without a seam above it)
             const int seamv = reads_seam ? __builtin_amdgcn_ds_bpermute((int)(((tb & 3u) << 6) + ((lane & 15u) << 2)), seam_grp) : 0;
             const bool steady = (t0 + 1u >= lact) && (t0 + 15u < n);     // (a truncated strip never leaves the reference)
