@@ -117,7 +117,7 @@ void        swmi_default_params(swmi_params *p);
  *                discards every other reference's alignments too); the alignment accessors of such chunks fail.
  * Further knobs: spin_us (how long a run polls its stream before it blocks, default 2000); col_chunks (0 automatic,
  * 1 never, N > 1 force up to N column chunks per pair: a launch of few pairs with long references is swept by several
- * wavefronts per pair); debug_strip_spins / debug_reverse_strips (tests of the strip pipeline's give-up path). */
+ * wavefronts per pair -- a read of more than 256 rows by several strip pipelines); debug_strip_spins / debug_reverse_strips (tests of the strip pipeline's give-up path). */
 int         swmi_set_option(swmi_ctx *ctx, const char *name, int64_t value);
 
 /* ---- staged path: upload once, run many times (what bench.py times) ------------- */
@@ -146,7 +146,7 @@ typedef struct swmi_timing {
     uint64_t cells;             /* sum of m*n over the pairs of the run            */
     uint64_t dir_bytes;         /* direction-field bytes written                   */
     uint32_t strip_fallbacks;   /* launches repeated with the one-wavefront sweep after the strip pipeline gave up */
-    uint32_t col_chunks;        /* column-chunk wavefronts the sweep of the run was split into (0: one per pair)    */
+    uint32_t col_chunks;        /* column chunks the sweep of the run was split into (0: one sweep per pair): one wavefront each, one strip pipeline each for reads of several strips */
     uint32_t resident_pairs;    /* pairs handled whole by one wavefront with the direction field in LDS             */
     uint32_t tfused_pairs;      /* pairs swept in the transposed layout and traced back by the same wavefront        */
 } swmi_timing;
