@@ -175,6 +175,14 @@ def test_strip_pipeline_give_up_falls_back_to_one_wave_sweep():
             assert b.score(r * len(reads) + q) == es
             assert b.alignments(r * len(reads) + q) == ea
     b.free()
+    # the same with every pair's sweep cut into column chunks (each chunk a strip pipeline of its own, swmi_device.h: StripItem)
+    ctx.set_option("col_chunks", 3)
+    b = ctx.upload(refs, reads).run()
+    assert b.timing().strip_fallbacks >= 1
+    assert [b.score(p) for p in range(6)] == [orc.opt_alignments((ref, read))[0] for ref in refs for read in reads]
+    assert b.alignments(0) == orc.opt_alignments((refs[0], reads[0]))[1]
+    b.free()
+    ctx.set_option("col_chunks", 0)
     # the knobs off again: the pipeline itself, no fallback
     ctx.set_option("debug_reverse_strips", 0)
     ctx.set_option("debug_strip_spins", 0)
