@@ -53,6 +53,9 @@ def parse_args():
     ap.add_argument("--top-k", type=int, default=8)
     ap.add_argument("--ref-len", type=int, default=2000)
     ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--in-flight", type=int, default=2,
+                    help="batches in flight per GPU (one context, stream and host thread each): 2 lets step k+1's sweep fill the tail "
+                         "of step k's traceback launch; 1 = strictly one step after the other")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--d2h-copy", action="store_true", help="fetch results with a D2H copy instead of zero-copy writes to pinned memory")
     ap.add_argument("--col-chunks", type=int, default=None, help="column chunks per pair (include/swmi.h): 0 automatic, 1 never, N force")
@@ -176,25 +179,38 @@ def main():
     cells_rank = sum(len(r) for r in refs) * m
     bytes_rank = sum(alg_bytes(m, len(r)) for r in refs)
 
-    ctx = sw.Context(local_rank)
-    # HIP events around the SWEEP of every timed step (roofline.achieved needs that kernel's duration live, inside the timed
-    # region); the traceback's duration is measured with the full set of events in a separate, labelled loop outside it --
-    # every marker packet costs the step ~3.5 us (profiles/r03/host_breakdown_headline.txt)
-    ctx.set_option("profiling", 2)
-    if args.mode is not None:
-        ctx.set_option("mode", args.mode)
-    if args.col_chunks is not None:
-        ctx.set_option("col_chunks", args.col_chunks)
-    if args.tfused is not None:
-        ctx.set_option("tfused", args.tfused)
-    if args.d2h_copy:
-        ctx.set_option("zero_copy", 0)
-    for kv in args.opt:
-        name, _, value = kv.partition("=")
-        ctx.set_option(name, int(value))
-    batch = ctx.upload(refs, reads)          # H2D happens here, outside the timed region
+    # Steps are passes over a batch whose inputs are resident in HBM.  --in-flight 2 (default) keeps TWO of them going, each with
+    # its own context (stream, host thread, workspace, pinned result block), the way a driver feeding partition after partition
+    # would: the traceback launch of step k ends with a few slow pairs on an almost empty chip (mean workgroup 54 k ticks,
+    # slowest 100 k), and the sweep of step k+1 -- one wavefront per SIMD -- runs in that tail.  Every step still does all of its
+    # work and delivers its results to host memory inside the timed region.
+    depth = max(1, args.in_flight)
+
+    def make_ctx():
+        c = sw.Context(local_rank)
+        # HIP events around the SWEEP of every EVENT_EVERY-th timed step (roofline.achieved needs that kernel's duration live,
+        # inside the timed region); the traceback's duration is measured with the full set of events in a separate, labelled
+        # loop outside it -- every marker packet costs the step ~3.5 us (profiles/r03/host_breakdown_headline.txt)
+        c.set_option("profiling", 2)
+        if args.mode is not None:
+            c.set_option("mode", args.mode)
+        if args.col_chunks is not None:
+            c.set_option("col_chunks", args.col_chunks)
+        if args.tfused is not None:
+            c.set_option("tfused", args.tfused)
+        if args.d2h_copy:
+            c.set_option("zero_copy", 0)
+        for kv in args.opt:
+            name, _, value = kv.partition("=")
+            c.set_option(name, int(value))
+        return c
+
+    ctxs = [make_ctx() for _ in range(depth)]
+    batches = [c.upload(refs, reads) for c in ctxs]          # H2D happens here, outside the timed region
+    ctx, batch = ctxs[0], batches[0]
     params = sw.make_params()
-    batch.run(params)
+    for b in batches:
+        b.run(params)
     mode = batch.pipeline_mode()             # the pipeline the library chose for this batch (or the one forced above)
     kernel_name = {0: "sw_fill_kernel", 1: "sw_sweep_winmax_kernel", 2: "sw_fill_score_kernel"}[mode]
     tfused = batch.timing().tfused_pairs == len(refs) * len(reads)      # option --tfused 1: sweep AND traceback in one launch
@@ -212,27 +228,44 @@ def main():
     # (swmi_batch_run_async), this thread submits the exchange of the previous shard's totals and collects the one
     # before, then waits for the run.  Every exchange of the timed steps has completed before the timed region ends.
     pending = []               # tickets of submitted, not yet collected exchanges
-    prev_totals = [None]
     last_result = [None]
+    order = []                 # slots in flight, oldest first
+    sampled_slot = [False] * depth
+    acc = {"fill_ms": 0.0, "launches": 0, "timed_steps": 0}
 
-    def step():
-        if reducer is None:
-            batch.run(params)
-            return
-        batch.run_async(params)
-        if prev_totals[0] is not None:
-            pending.append(reducer.submit(prev_totals[0], gids))
+    def retire(i):
+        """completes the run of slot i: its results are in host memory; its totals go to the exchange"""
+        if depth > 1:
+            batches[i].wait()
+        if sampled_slot[i]:
+            t = batches[i].timing()
+            acc["fill_ms"] += t.fill_ms; acc["launches"] += t.fill_launches; acc["timed_steps"] += 1
+            sampled_slot[i] = False
+        if reducer is not None:
+            pending.append(reducer.submit(batches[i].ref_totals(), gids))
             if len(pending) > 1:
                 last_result[0] = reducer.collect(pending.pop(0))
-        batch.wait()
-        prev_totals[0] = batch.ref_totals()
+
+    def step(k, timed=False):
+        i = k % depth
+        if i in order:
+            order.remove(i)
+            retire(i)
+        # the sweep kernel is bracketed by HIP events on every EVENT_EVERY-th step of the timed region (the two marker packets
+        # cost a step 8 us, 5 % of it: profiles/r03/host_breakdown_headline.txt); its average duration over those launches is what
+        # roofline.achieved divides by, and rocprofv3's kernel trace of the same command must agree (profiles/)
+        sampled_slot[i] = timed and k % EVENT_EVERY == 0
+        ctxs[i].set_option("profiling", 2 if sampled_slot[i] else 0)
+        if depth > 1:
+            batches[i].run_async(params)
+            order.append(i)
+        else:
+            batches[0].run(params)
+            retire(0)
 
     def drain():
-        if reducer is None:
-            return None
-        if prev_totals[0] is not None:
-            pending.append(reducer.submit(prev_totals[0], gids))
-            prev_totals[0] = None
+        while order:
+            retire(order.pop(0))
         while pending:
             last_result[0] = reducer.collect(pending.pop(0))
         return last_result[0]
@@ -242,26 +275,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    for k in range(args.warmup):
+        step(k)
     drain()
     sync()
-    fill_ms = 0.0
-    launches = timed_steps = 0
     t0 = time.perf_counter()
     for k in range(args.steps):
-        # the sweep kernel is bracketed by HIP events on every EVENT_EVERY-th step of the timed region (the two marker packets
-        # cost a step 8 us, 5 % of it: profiles/r03/host_breakdown_headline.txt); its average duration over those launches is what
-        # roofline.achieved divides by, and rocprofv3's kernel trace of the same command must agree (profiles/)
-        sampled = k % EVENT_EVERY == 0
-        ctx.set_option("profiling", 2 if sampled else 0)
-        step()
-        if sampled:
-            t = batch.timing()
-            fill_ms += t.fill_ms; launches += t.fill_launches; timed_steps += 1
+        step(k, timed=True)
     last = drain()
     sync()
     elapsed = time.perf_counter() - t0
+    fill_ms, launches, timed_steps = acc["fill_ms"], acc["launches"], acc["timed_steps"]
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -303,13 +327,16 @@ def main():
     ctx.set_option("profiling", 1)
     tb_steps = max(5, min(args.steps, 20))
     tb_ms = d2h_ms = 0.0
+    solo_fill_ms, solo_launches = 0.0, 0
     for _ in range(tb_steps):
         batch.run(params)
         t = batch.timing()
         tb_ms += t.traceback_ms; d2h_ms += t.d2h_ms
+        solo_fill_ms += t.fill_ms; solo_launches += t.fill_launches
     tb_ms *= args.steps / tb_steps; d2h_ms *= args.steps / tb_steps        # (reported per step below, like the sweep's)
     ctx.set_option("profiling", 2)
     gpu_scores, gpu_naln = batch.pair_results()
+    same = all(np.array_equal(gpu_scores, b.pair_results()[0]) and np.array_equal(gpu_naln, b.pair_results()[1]) for b in batches[1:])
     winner = int(np.argmax(batch.ref_totals()))
 
     if rank == 0:
@@ -347,16 +374,23 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "alignments_per_s": round(len(refs) * len(reads) * world * args.steps / elapsed, 1),
+            "in_flight": depth,
+            "ms_per_step_one_in_flight": round(ms_noev, 4),
+            "gcups_one_in_flight": round(cells_rank / (ms_noev * 1e-3) / 1e9, 3),
             "ms_per_step_materialised": round(ms_mat, 4),
             "ms_per_step_without_events": round(ms_noev, 4),
             "materialised": {"what": "run (both aligned strings of every alignment are written by the traceback kernels) + the index over "
                                      "every alignment (swmi_batch_materialise_all): everything OptAlignments returns; rank 0, no events, "
-                                     "outside the timed region", "steps": mat_steps,
+                                     "one step after the other, outside the timed region", "steps": mat_steps,
                              "alignments": int(n_aln_all), "chars": int(n_chars),
                              "gcups": round(cells_rank / (ms_mat * 1e-3) / 1e9, 3)},
             "config": {"workload": "configs[1]: 1 read x %d bp vs %d refs x %d bp per GPU, scores 5/-3/-4, mode %d: %s"
                                    % (m, len(refs), args.ref_len, mode, "transposed sweep (column checkpoints) + block re-sweeps + walks + result records, ONE kernel (option tfused)" if tfused else WORKLOAD_OF_MODE[mode]),
                        "pairs_per_gpu": len(refs) * len(reads), "cells_per_step_per_gpu": cells_rank,
+                       "steps_in_flight": "%d per GPU: each step is one full pass over one resident batch (own context, stream, workspace and "
+                                          "pinned result block); with 2, step k+1's sweep runs in the tail of step k's traceback launch. "
+                                          "ms_per_step_one_in_flight / gcups_one_in_flight: the same steps strictly one after the other" % depth
+                                          if depth > 1 else "1: strictly one step after the other",
                        "parallelism": "references sharded over %d rank(s); max/top-K reduce %s"
                                       % (world, ("over gloo (one-GPU rehearsal)" if one_gpu else "over RCCL") if world > 1 else "local")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -366,10 +400,14 @@ def main():
                          "kernel_gcups": round(cells_rank / fill_avg_s / 1e9, 2) if fill_avg_s > 0 else None,
                          "traceback_avg_ms": round(tb_ms / args.steps, 4), "d2h_avg_ms": round(d2h_ms / args.steps, 4),
                          "kernel_timed_launches": launches,
-                         "kernel_timing": "HIP events on the library's stream around the sweep kernel of every %d-th timed step (%d of %d steps)" % (EVENT_EVERY, timed_steps, args.steps),
+                         "kernel_timing": "HIP events on the launching context's stream around the sweep kernel of every %d-th timed step (%d of %d steps)%s" % (
+                             EVENT_EVERY, timed_steps, args.steps, "; with two steps in flight the sweep shares the chip with the other step's traceback" if depth > 1 else ""),
+                         "one_in_flight": {"kernel_avg_ms": round(solo_fill_ms / max(solo_launches, 1), 4),
+                                           "frac": round(bytes_rank / (solo_fill_ms / max(solo_launches, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if solo_fill_ms > 0 else None,
+                                           "what": "the same kernel's duration with one step after the other (the loop that times the traceback)"},
                          "traceback_note": "measured in %d extra steps with every stage bracketed by events, outside the timed region "
                                            "(the timed steps bracket the sweep only)" % tb_steps},
-            "check": {"winner_ref": winner, "winner_total": batch.ref_total(winner)},
+            "check": {"winner_ref": winner, "winner_total": batch.ref_total(winner), "in_flight_batches_identical": bool(same)},
         }
         if reduce_ms is not None:
             out["reduce_ms"] = round(reduce_ms, 4)
@@ -383,8 +421,10 @@ def main():
             out["cpu_baseline"] = base
             out["check"].update(chk)
         print(json.dumps(out), flush=True)
-    batch.free()
-    ctx.close()
+    for b in batches:
+        b.free()
+    for c in ctxs:
+        c.close()
     if world > 1:
         dist.barrier()
     if world > 1 or rehearse_rccl:
