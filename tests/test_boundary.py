@@ -120,6 +120,44 @@ def test_two_contexts_on_two_threads():
 
 
 @pytest.mark.gpu
+def test_two_batches_in_flight_alternating():
+    """bench.py's step loop: two batches in flight on one GPU, one context (stream, host thread, result block) each, started
+    alternately with swmi_batch_run_async so that one batch's sweep runs beside the other's traceback.  Different data in
+    the two batches; every step's results -- scores, counts, every alignment string of sampled pairs -- against the oracle."""
+    from oracle import sw_oracle as orc
+    jobs = [synth.config_1k(n_refs=400, ref_len=900, read_len=150, seed=21),
+            synth.config_1k(n_refs=350, ref_len=1200, read_len=120, seed=22)]
+    want = []
+    for refs, reads in jobs:
+        r = orc.bench(refs, reads, nthreads=8, per_pair=True)
+        want.append((r["pair_score"], r["pair_naln"]))
+    ctxs = [sw.Context(0), sw.Context(0)]
+    bs = [c.upload(*job) for c, job in zip(ctxs, jobs)]
+    in_flight = [False, False]
+
+    def retire(i):
+        bs[i].wait()
+        sc, na = bs[i].pair_results()
+        assert [int(x) for x in sc] == want[i][0] and [int(x) for x in na] == want[i][1]
+        refs, reads = jobs[i]
+        for p in (0, 7, len(refs) - 1):
+            assert bs[i].alignments(p) == orc.opt_alignments((refs[p], reads[0]))[1]
+
+    for k in range(12):
+        i = k % 2
+        if in_flight[i]:
+            retire(i)
+        bs[i].run_async()
+        in_flight[i] = True
+    for i in range(2):
+        retire(i)
+    for b in bs:
+        b.free()
+    for c in ctxs:
+        c.close()
+
+
+@pytest.mark.gpu
 def test_repeated_runs_header_ring_and_deferred_record_stream():
     """Host-side bookkeeping of repeated runs (swmi_api.cpp): a launch of whole-pair kernels only takes its arena header from a
     ring of 1024 zeroed slots (1100 runs wrap it); the record stream of a single-launch run stays in the pinned block until an
