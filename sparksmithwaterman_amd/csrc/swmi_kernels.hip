@@ -960,7 +960,10 @@ sw_fill_kernel(const FillArgs A) { fill_entry<SWMI_MODE_FIELD>(A); }
 extern "C" __global__ void __launch_bounds__(WAVE * FILL_WAVES)
 sw_fill_score_kernel(const FillArgs A) { fill_entry<SWMI_MODE_SCORE>(A); }
 
-extern "C" __global__ void __launch_bounds__(WAVE * FILL_WAVES)
+// (at most 128 VGPRs -- 14 spills, none in the fast stream: with two batches in flight this kernel's wavefront shares its SIMD
+//  with the other batch's traceback wavefronts, 128 VGPRs each: three of them fit beside it, at 137 only two.  Two in flight
+//  0.124 -> 0.119 ms per step, one at a time 0.1655 -> 0.167: profiles/r03/ab_sweep_128vgpr_after_lds.txt)
+extern "C" __global__ void __launch_bounds__(WAVE * FILL_WAVES) __attribute__((amdgpu_waves_per_eu(4, 4)))
 sw_sweep_winmax_kernel(const FillArgs A) { fill_entry<SWMI_MODE_WINMAX>(A); }
 
 // mode 1, reads of several strips: one wavefront per (pair, strip).  The items are ordered so that a strip's producer
