@@ -3,7 +3,10 @@
 
 A "step" is one pass of the hot path over one batch: score sweep + tied-maximum lists + device traceback for every
 (reference, read) pair, compact result records written to host memory, and (N > 1) the max/top-K reduce over RCCL.
-Inputs are resident in HBM before the timed region starts.
+Inputs are resident in HBM before the timed region starts.  Steps are independent of each other, so two are kept in flight per
+GPU (--in-flight, default 2), each a full pass over its own resident copy of the batch with its own context, stream, workspace
+and pinned result block: the sweep of one runs beside the tail of the other's traceback launch.  `value` / `ms_per_step` are that
+loop's; `gcups_one_in_flight` / `ms_per_step_one_in_flight` the same steps strictly one after the other.
 
 N = 1 workload = BASELINE.json configs[1]: one 150 bp read x 1,000 synthetic 2 kbp references (3.0e8 cells,
 SplitMix64 seed 1).  N > 1: every rank holds its own 1,000-reference shard (weak scaling, references sharded
