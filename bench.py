@@ -237,23 +237,28 @@ def main():
     acc = {"fill_ms": 0.0, "launches": 0, "timed_steps": 0}
 
     def retire(i):
-        """completes the run of slot i: its results are in host memory; its totals go to the exchange"""
+        """completes the run of slot i: its results are in host memory; returns its totals for the exchange"""
         if depth > 1:
             batches[i].wait()
         if sampled_slot[i]:
             t = batches[i].timing()
             acc["fill_ms"] += t.fill_ms; acc["launches"] += t.fill_launches; acc["timed_steps"] += 1
             sampled_slot[i] = False
-        if reducer is not None:
-            pending.append(reducer.submit(batches[i].ref_totals(), gids))
+        return batches[i].ref_totals() if reducer is not None else None
+
+    def exchange(totals):
+        """the path's one exchange step for a retired shard (submitted now, collected one step later)"""
+        if totals is not None:
+            pending.append(reducer.submit(totals, gids))
             if len(pending) > 1:
                 last_result[0] = reducer.collect(pending.pop(0))
 
     def step(k, timed=False):
         i = k % depth
+        totals = None
         if i in order:
             order.remove(i)
-            retire(i)
+            totals = retire(i)          # (taken before the slot's next run overwrites its result block)
         # the sweep kernel is bracketed by HIP events on every EVENT_EVERY-th step of the timed region (the two marker packets
         # cost a step 8 us, 5 % of it: profiles/r03/host_breakdown_headline.txt); its average duration over those launches is what
         # roofline.achieved divides by, and rocprofv3's kernel trace of the same command must agree (profiles/)
@@ -262,13 +267,14 @@ def main():
         if depth > 1:
             batches[i].run_async(params)
             order.append(i)
+            exchange(totals)            # ... and exchanged while both slots are running
         else:
             batches[0].run(params)
-            retire(0)
+            exchange(retire(0))
 
     def drain():
         while order:
-            retire(order.pop(0))
+            exchange(retire(order.pop(0)))
         while pending:
             last_result[0] = reducer.collect(pending.pop(0))
         return last_result[0]
