@@ -224,7 +224,9 @@ def main():
 
     reducer = None
     if world > 1 or rehearse_rccl:
-        reducer = swd.MaxReducer("cpu" if one_gpu else dev, always_exchange=rehearse_rccl)    # buffers allocated once; one RCCL all-gather per step
+        # buffers allocated once; one RCCL all-gather per step, collected three steps later: a rank that is briefly late does
+        # not stall the others' step loops (every exchange of the timed steps still completes inside the timed region)
+        reducer = swd.MaxReducer("cpu" if one_gpu else dev, always_exchange=rehearse_rccl, depth=4)
 
     # The path's one exchange step (max total + its references) is done for shard k-1 while the GPU works on shard k,
     # the way a driver streaming shards would: the run is started on the library's own host thread
@@ -250,7 +252,7 @@ def main():
         """the path's one exchange step for a retired shard (submitted now, collected one step later)"""
         if totals is not None:
             pending.append(reducer.submit(totals, gids))
-            if len(pending) > 1:
+            if len(pending) > 3:
                 last_result[0] = reducer.collect(pending.pop(0))
 
     def step(k, timed=False):
